@@ -1,0 +1,187 @@
+/*
+ * wam.h - C ABI of libwam_hip.so, the MI355X (gfx950) backend that replaces the
+ * export-render and analysis hot path of entrepeneur4lyf/Web-Audio-Mastering.
+ *
+ * Every entry point cites the reference interface it replaces (paths under the
+ * reference checkout, file:line).  Conventions, all entry points:
+ *   - plain C, no exceptions; return 0 (WAM_OK) or a negative wam_status, and
+ *     wam_last_error() then holds a message for the calling thread;
+ *   - audio is planar float32: `ch[c]` points at `n` samples of channel c;
+ *   - `*_dev` entry points take DEVICE pointers (hipMalloc memory) and enqueue on
+ *     the HIP stream given (NULL = default stream); the others take HOST pointers,
+ *     copy in, run the same kernels, copy out and synchronise;
+ *   - the caller owns every buffer; inputs are never written (the reference's
+ *     interface transfers copies, web/workers/worker-interface.js:116-132);
+ *   - there is no CPU fallback: without a usable HIP device every compute entry
+ *     point returns WAM_ERR_NO_DEVICE.
+ */
+#ifndef WAM_H
+#define WAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  WAM_OK = 0,
+  WAM_ERR_INVALID = -1,    /* bad argument (NULL, n <= 0, nch not 1..2, ...) */
+  WAM_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure at init */
+  WAM_ERR_HIP = -3,        /* a HIP call failed; message in wam_last_error() */
+  WAM_ERR_NOMEM = -4,
+  WAM_ERR_CANCELLED = -5,  /* progress callback returned non-zero ('Cancelled', web/ui/encoder.js:195-197) */
+  WAM_ERR_TOO_LARGE = -6
+} wam_status;
+
+/* Flat settings object of the reference UI, web/ui/controls.js:66-89 (same
+ * meaning per key; booleans are 0/1).  auto_level is accepted and ignored, as
+ * in the reference (read at controls.js:80, never consumed). */
+typedef struct wam_settings {
+  int32_t normalize_loudness;   /* normalizeLoudness */
+  double  target_lufs;          /* targetLufs; 0 disables, dsp-worker.js:1602 */
+  int32_t true_peak_limit;      /* truePeakLimit */
+  double  true_peak_ceiling;    /* truePeakCeiling dB; 0 or NaN means -1, dsp-worker.js:1612 */
+  int32_t clean_low_end;        /* cleanLowEnd: 30 Hz HPF */
+  int32_t glue_compression;     /* glueCompression */
+  int32_t deharsh;              /* deharsh */
+  double  stereo_width;         /* stereoWidth in percent (100 = unchanged); NaN means 100 */
+  int32_t center_bass;          /* centerBass */
+  int32_t cut_mud;              /* cutMud */
+  int32_t add_air;              /* addAir (exciter) */
+  int32_t tape_warmth;          /* tapeWarmth */
+  int32_t auto_level;           /* autoLevel (ignored) */
+  int32_t add_punch;            /* addPunch */
+  double  input_gain;           /* inputGain dB */
+  double  eq_low, eq_low_mid, eq_mid, eq_high_mid, eq_high; /* dB */
+} wam_settings;
+
+enum { WAM_MODE_PREVIEW = 0, WAM_MODE_EXPORT = 1 }; /* dsp-worker.js:1473,1530 */
+
+typedef struct wam_result {
+  double lufs;            /* result.lufs          (dsp-worker.js:1649,1660) */
+  double measured_lufs;   /* result.measuredLufs  (dsp-worker.js:1661)      */
+  double true_peak_db;    /* findTruePeak of the output (extra; true-peak.js:46) */
+  double lufs_in;         /* loudness measured by stage 8 before the gain (normalizer.js:39); NaN if stage 8 did not run */
+  double gain_db;         /* stage-8 gain applied, 0 if none (normalizer.js:50) */
+} wam_result;
+
+/* Progress callback, same fractions/status strings as sendProgress(),
+ * dsp-worker.js:69-71,1475-1664.  Return non-zero to cancel. */
+typedef int (*wam_progress_cb)(double progress, const char* status, void* user);
+
+/* ---- library ------------------------------------------------------------ */
+const char* wam_last_error(void);
+/* Initialise device `device` (hipSetDevice) for the calling thread; idempotent.
+ * Replaces DSPWorkerInterface.init(), worker-interface.js:23. */
+int wam_init(int device);
+int wam_device_count(int* count);
+const char* wam_version(void);
+
+/* ---- metering ----------------------------------------------------------- */
+/* measureLUFS(audioBuffer, fallbackLufs), web/lib/dsp/lufs.js:17-82 (worker twin
+ * dsp-worker.js:77-137, message MEASURE_LUFS :1355).  `lufs` gets -INFINITY for
+ * silence and `fallback` for audio shorter than 0.4 s.  Optional outputs (may be
+ * NULL): block_ms[nblocks] mean-square per 400 ms block; gate_mask[nblocks]
+ * 0 = dropped by absolute gate, 1 = dropped by relative gate, 2 = kept;
+ * nblocks_out = number of blocks.  Capacity of both arrays: wam_lufs_num_blocks(). */
+int wam_measure_lufs(const float* const* ch, int nch, int64_t n, double sample_rate,
+                     double fallback, double* lufs,
+                     double* block_ms, uint8_t* gate_mask, int64_t* nblocks_out);
+int64_t wam_lufs_num_blocks(int64_t n, double sample_rate);
+
+/* findTruePeak(audioBuffer), web/lib/dsp/true-peak.js:46-71 (worker twin
+ * dsp-worker.js:169-192, message FIND_TRUE_PEAK :1361).  dBTP, -INFINITY for silence. */
+int wam_true_peak_db(const float* const* ch, int nch, int64_t n, double* dbtp);
+
+/* One pass over the input for both numbers (what app.js:865-866 asks for on load). */
+int wam_meter(const float* const* ch, int nch, int64_t n, double sample_rate,
+              double fallback, double* lufs, double* dbtp);
+
+/* detectDCOffsetBuffer / removeDCOffset, web/lib/dsp/dc-offset.js:38-77: mean per
+ * channel into dc[nch]; when `remove` is set, out[c] = ch[c] - dc[c] where
+ * |dc[c]| > 1e-10 (copy otherwise).  out may be NULL when remove == 0. */
+int wam_dc_offset(const float* const* ch, int nch, int64_t n, double* dc, int remove, float* const* out);
+
+/* ---- rendering ---------------------------------------------------------- */
+/* RENDER_FULL_CHAIN, web/workers/dsp-worker.js:1468-1667, reached through
+ * DSPWorkerInterface.renderFullChain(), worker-interface.js:259-277.
+ * out[c] receives n samples.  Differences from the reference, both documented in
+ * the 5-band EQ / Cut Mud stage works (the reference's is broken,
+ * SURVEY.md 0.1) and follows the Web Audio biquad formulas with the parameters of
+ * dsp-worker.js:1236-1264. */
+int wam_render_chain(const float* const* ch, int nch, int64_t n, double sample_rate,
+                     const wam_settings* settings, int mode, float* const* out,
+                     wam_result* result, wam_progress_cb progress, void* user);
+
+/* Batch form: ntracks tracks of identical shape, track t channel c at
+ * in[t * nch + c] / out[t * nch + c]; results[t].  Tracks are independent
+ * (SURVEY.md 8e); the caller shards track ranges over devices, one process or
+ * thread per device, and calls this once per shard. */
+int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sample_rate,
+                     const wam_settings* settings, int mode, float* const* out, wam_result* results);
+
+/* Device-resident batch: `in_dev` / `out_dev` are device pointers to
+ * [ntracks][nch][n] float32, contiguous.  Enqueues on `stream` and returns after
+ * the results have been copied back (it synchronises the stream once). */
+int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
+                         const wam_settings* settings, int mode, float* out_dev,
+                         wam_result* results, void* stream);
+int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
+                        double fallback, double* lufs, double* dbtp, void* stream);
+
+/* normalizeChannelsToLUFS, dsp-worker.js:457-527 (message NORMALIZE :1367;
+ * DSPWorkerInterface.normalize(), worker-interface.js:197).  Applies the limiter
+ * when the projected peak exceeds ceiling_db. */
+typedef struct wam_normalize_result {
+  double current_lufs, final_lufs, peak_db, gain_applied_db;
+  int32_t limiter_applied;
+  int32_t measured;   /* 0 when loudness was not finite and the input was returned unchanged */
+} wam_normalize_result;
+int wam_normalize(const float* const* ch, int nch, int64_t n, double sample_rate,
+                  double target_lufs, double ceiling_db, float* const* out, wam_normalize_result* res);
+
+/* applyLookaheadLimiterToChannels, dsp-worker.js:286-452 (message APPLY_LIMITER
+ * :1380; DSPWorkerInterface.applyLimiter(), worker-interface.js:227). */
+int wam_limiter(const float* const* ch, int nch, int64_t n, double sample_rate,
+                double ceiling_linear, double lookahead_ms, double release_ms, double knee_db,
+                int preserve_transients, float* const* out);
+
+/* Single stages, same arithmetic as inside wam_render_chain (lib/dsp/index.js names). */
+int wam_final_filters(const float* const* ch, int nch, int64_t n, double sample_rate,
+                      int highpass, int lowpass, float* const* out);          /* final-filters.js:96 */
+int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sample_rate,
+                  double ceiling_db, double lookahead_ms, double release_ms, double drive,
+                  float* const* out);                                         /* soft-clipper.js:165 */
+int wam_glue_compressor(const float* const* ch, int nch, int64_t n, double sample_rate,
+                        double threshold_db, double ratio, double attack_s, double release_s,
+                        float* const* out);                                   /* dsp-worker.js:1272 */
+int wam_stereo(const float* const* ch, int64_t n, double sample_rate, double width, int bass_mono,
+               double bass_freq, float* const* out);                          /* dsp-worker.js:1122 */
+int wam_parametric_eq(const float* const* ch, int nch, int64_t n, double sample_rate,
+                      const double gains_db[5], int cut_mud, float* const* out); /* dsp-worker.js:1222 */
+int wam_exciter(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out);   /* exciter.js:223 */
+int wam_deharsh(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out);   /* dynamic-processor.js:595 ('mastering') */
+int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out); /* multiband-saturation.js:365 */
+int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out); /* multiband-transient.js:15 */
+
+/* encodeWAV 24-bit branch, web/ui/encoder.js:116-123: interleaved little-endian
+ * 24-bit PCM, 3 * nch * n bytes, no header (wam_wav_header writes the 44 bytes of
+ * encoder.js:74-86). */
+int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out);
+int wam_wav_header(int nch, int64_t n, int sample_rate, int bits, uint8_t out44[44]);
+
+/* Spectrogram.process() per frame, web/ui/spectrogram.js:113-143,217-257, batched:
+ * frames start at f * hop of the mono mix 0.5 (L + R) (the analyser's down-mix),
+ * periodic Hann, dB per bin as spectrogram.js:135-142.  out[nframes][nfft / 2];
+ * nframes = (n - nfft) / hop + 1.  columns (optional) [nframes][256] = the
+ * log-frequency column of updateLatestColumn(), spectrogram.js:177-215. */
+int wam_stft_db(const float* const* ch, int nch, int64_t n, double sample_rate, int nfft, int hop,
+                float* out_db, float* columns);
+int64_t wam_stft_num_frames(int64_t n, int nfft, int hop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAM_H */
