@@ -1,0 +1,139 @@
+// api.hip - the C ABI of libwam_hip.so (include/wam.h): argument checking, host
+// <-> device staging, and the calls into the kernel launchers.  There is no CPU
+// path here: every compute entry point needs a HIP device.
+#include "meter_host.hpp"
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace wam {
+
+static thread_local std::string g_err;
+static thread_local int g_device = -1;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_err = buf;
+}
+
+int ensure_device() {
+  if (g_device >= 0) {
+    if (hipSetDevice(g_device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g_device); return WAM_ERR_NO_DEVICE; }
+    return WAM_OK;
+  }
+  return wam_init(0);
+}
+
+static int check_audio(const float* const* ch, int nch, int64_t n) {
+  if (!ch || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
+  for (int c = 0; c < nch; c++) if (!ch[c] && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
+
+// host planar channels -> contiguous device [nch][n]
+static int upload(const float* const* ch, int nch, int64_t n, DevBuf& buf, hipStream_t stream) {
+  int rc = buf.alloc(sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1));
+  if (rc) return rc;
+  for (int c = 0; c < nch && n > 0; c++)
+    WAM_HIP(hipMemcpyAsync(buf.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream));
+  return WAM_OK;
+}
+
+static int meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sr, double fallback,
+                     double* lufs, double* dbtp, double* block_ms, uint8_t* gate_mask, int64_t* nblocks_out, hipStream_t stream) {
+  MeterPlan pl;
+  int rc = make_meter_plan(nch, n, sr, fallback, &pl);
+  if (rc) return rc;
+  const bool want_mask = gate_mask != nullptr;
+  DevBuf scratch;
+  rc = scratch.alloc(meter_scratch_bytes(pl, ntracks, want_mask));
+  if (rc) return rc;
+  MeterScratch s;
+  carve_meter_scratch(pl, ntracks, want_mask, scratch.p, &s);
+  rc = enqueue_meter(in_dev, ntracks, pl, n, s, stream);
+  if (rc) return rc;
+  std::vector<GateOut> g(ntracks);
+  WAM_HIP(hipMemcpyAsync(g.data(), s.gate, sizeof(GateOut) * ntracks, hipMemcpyDeviceToHost, stream));
+  if (block_ms && pl.nblocks > 0) WAM_HIP(hipMemcpyAsync(block_ms, s.blocks, sizeof(double) * pl.nblocks, hipMemcpyDeviceToHost, stream));
+  if (gate_mask && pl.nblocks > 0) WAM_HIP(hipMemcpyAsync(gate_mask, s.mask, (size_t)pl.nblocks, hipMemcpyDeviceToHost, stream));
+  WAM_HIP(hipStreamSynchronize(stream));
+  for (int t = 0; t < ntracks; t++) {
+    if (lufs) lufs[t] = finish_lufs(pl, g[t]);
+    if (dbtp) dbtp[t] = finish_peak_db(g[t]);
+  }
+  if (nblocks_out) *nblocks_out = pl.too_short ? 0 : pl.nblocks;
+  return WAM_OK;
+}
+
+}  // namespace wam
+
+using namespace wam;
+
+extern "C" {
+
+const char* wam_last_error(void) { return g_err.c_str(); }
+const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
+
+int wam_device_count(int* count) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
+  if (count) *count = n;
+  return WAM_OK;
+}
+
+int wam_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (this backend has no CPU path)");
+    return WAM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return WAM_ERR_INVALID; }
+  if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
+  g_device = device;
+  return WAM_OK;
+}
+
+int64_t wam_lufs_num_blocks(int64_t n, double sample_rate) {
+  if (!(sample_rate > 0) || n <= 0) return 0;
+  const int64_t bs = (int64_t)std::floor(sample_rate * 0.4), hop = (int64_t)std::floor(sample_rate * 0.4 * (1 - 0.75));
+  if (hop <= 0 || n < bs) return 0;
+  return (n - bs) / hop + 1;
+}
+
+int wam_measure_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double fallback, double* lufs,
+                     double* block_ms, uint8_t* gate_mask, int64_t* nblocks_out) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  if (!lufs) { set_error("lufs is NULL"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  DevBuf in;
+  rc = upload(ch, nch, n, in, nullptr); if (rc) return rc;
+  return meter_dev(in.as<float>(), 1, nch, n, sample_rate, fallback, lufs, nullptr, block_ms, gate_mask, nblocks_out, nullptr);
+}
+
+int wam_true_peak_db(const float* const* ch, int nch, int64_t n, double* dbtp) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  if (!dbtp) { set_error("dbtp is NULL"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  DevBuf in;
+  rc = upload(ch, nch, n, in, nullptr); if (rc) return rc;
+  return meter_dev(in.as<float>(), 1, nch, n, 48000.0, -14.0, nullptr, dbtp, nullptr, nullptr, nullptr, nullptr);
+}
+
+int wam_meter(const float* const* ch, int nch, int64_t n, double sample_rate, double fallback, double* lufs, double* dbtp) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  rc = ensure_device(); if (rc) return rc;
+  DevBuf in;
+  rc = upload(ch, nch, n, in, nullptr); if (rc) return rc;
+  return meter_dev(in.as<float>(), 1, nch, n, sample_rate, fallback, lufs, dbtp, nullptr, nullptr, nullptr, nullptr);
+}
+
+int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate, double fallback,
+                        double* lufs, double* dbtp, void* stream) {
+  if (!in_dev || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
+  int rc = ensure_device(); if (rc) return rc;
+  return meter_dev(in_dev, ntracks, nch, n, sample_rate, fallback, lufs, dbtp, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

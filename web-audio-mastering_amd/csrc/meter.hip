@@ -1,0 +1,164 @@
+// meter.hip - stand-alone metering kernels (a3, a6) and the gating kernel.
+//
+// k_meter: one workgroup per (track, channel); one read of the input yields the
+//          per-hop K-weighted energy sums and the channel's true peak.
+//          Algorithmic traffic: 4 B per sample-channel.
+// k_gate : one workgroup per track; 400 ms block energies from four hops, then
+//          the absolute / relative gates of lufs.js:68-81 with the reference's
+//          sequential summation order.
+#include "meter_host.hpp"
+#include <cmath>
+#include <cstring>
+
+namespace wam {
+
+__global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in, int64_t n, const MeterPlan* __restrict__ plan,
+                                                    double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks) {
+  __shared__ double lds[kMeterLds];
+  __shared__ float ctx[2 * (kThreads + 1) * 3];
+  const MeterPlan& pl = *plan;
+  const int64_t chan = blockIdx.x;
+  const float* x = in + chan * n;
+  double* hs = hopsums + chan * hop_stride;
+  MeterState m;
+  meter_init(m, pl, 0);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    float v[C], xp[3];
+    load_chunk(x, n, base, v);
+    const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
+    prev_context<3>(last, xp, ctx, (int)(t & 1), t == 0);
+    meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hs);
+  }
+  meter_finish(m, lds, peaks + chan);
+}
+
+// Gating (lufs.js:57-81).  blocks: scratch [ntracks][nblocks] (always written).
+__global__ __launch_bounds__(256) void k_gate(const double* __restrict__ hopsums, int64_t hop_stride, const double* __restrict__ peaks,
+                                              const MeterPlan* __restrict__ plan, double* __restrict__ blocks, uint8_t* __restrict__ mask,
+                                              GateOut* __restrict__ out) {
+  const MeterPlan& pl = *plan;
+  const int64_t trk = blockIdx.x;
+  const int nch = pl.nch;
+  const int64_t nb = pl.nblocks;
+  double* bl = blocks + trk * (nb > 0 ? nb : 1);
+  const double denom = (double)(pl.block * nch);
+  for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    double ss = 0;
+    for (int c = 0; c < nch; c++) {
+      const double* hs = hopsums + (trk * nch + c) * hop_stride;
+      ss += ((hs[b] + hs[b + 1]) + hs[b + 2]) + hs[b + 3];
+    }
+    bl[b] = ss / denom;
+  }
+  __syncthreads();
+  __shared__ double stage[2048];
+  __shared__ double s_mean1;
+  double s1 = 0, s2 = 0;
+  int64_t c1 = 0, c2 = 0;
+  // pass 1: absolute gate, sequential sum in block order
+  for (int64_t b0 = 0; b0 < nb; b0 += 2048) {
+    const int64_t m = nb - b0 < 2048 ? nb - b0 : 2048;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) stage[i] = bl[b0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int64_t i = 0; i < m; i++) { const double v = stage[i]; if (v > 1e-7) { s1 += v; c1++; } }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_mean1 = c1 > 0 ? s1 / (double)c1 : 0.0;
+  __syncthreads();
+  const double thr = s_mean1 * 0.1;
+  for (int64_t b0 = 0; b0 < nb; b0 += 2048) {
+    const int64_t m = nb - b0 < 2048 ? nb - b0 : 2048;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+      const double v = bl[b0 + i];
+      stage[i] = v;
+      if (mask) mask[trk * (nb > 0 ? nb : 1) + b0 + i] = (v > 1e-7) ? ((v > thr) ? 2 : 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (int64_t i = 0; i < m; i++) { const double v = stage[i]; if (v > 1e-7 && v > thr) { s2 += v; c2++; } }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    GateOut o;
+    o.c1 = c1; o.c2 = c2; o.nblocks = nb;
+    o.mean2 = c2 > 0 ? s2 / (double)c2 : 0.0;
+    double pk = 0;
+    for (int c = 0; c < nch; c++) pk = fmax(pk, peaks[trk * nch + c]);
+    o.peak = pk;
+    out[trk] = o;
+  }
+}
+
+// ---- host side -------------------------------------------------------------
+int make_meter_plan(int nch, int64_t n, double sr, double fallback, MeterPlan* pl) {
+  if (!(sr > 0) || n < 0 || nch < 1) { set_error("bad meter arguments"); return WAM_ERR_INVALID; }
+  std::memset(pl, 0, sizeof(*pl));
+  pl->shelf = k_high_shelf(sr, 1681.97, 4.0, 0.71);      // constants.js:7-13
+  pl->hp = rbj_pass(sr, 38.14, 0.5, true);
+  pl->block = (int64_t)std::floor(sr * 0.4);                         // lufs.js:53
+  pl->hop = (int64_t)std::floor(sr * 0.4 * (1 - 0.75));              // lufs.js:54
+  pl->nch = nch;
+  pl->fallback = fallback;
+  pl->too_short = ((double)n / sr < 0.4) ? 1 : 0;                    // lufs.js:23
+  if (pl->hop < C || pl->block != 4 * pl->hop) {
+    set_error("sample rate %.3f Hz: the 400 ms block (%lld) is not four 100 ms hops (%lld); unsupported", sr,
+              (long long)pl->block, (long long)pl->hop);
+    return WAM_ERR_INVALID;
+  }
+  pl->nhops = n / pl->hop;
+  pl->nblocks = 0;
+  for (int64_t st = 0; st + pl->block <= n; st += pl->hop) pl->nblocks++;
+  return WAM_OK;
+}
+
+double finish_lufs(const MeterPlan& pl, const GateOut& g) {
+  if (pl.too_short) return pl.fallback;
+  if (g.nblocks == 0 || g.c1 == 0 || g.c2 == 0) return -INFINITY;
+  return -0.691 + 10 * std::log10(g.mean2);                          // lufs.js:81
+}
+double finish_peak_db(const GateOut& g) { return g.peak > 0 ? 20 * std::log10(g.peak) : -INFINITY; }   // true-peak.js:70
+
+size_t meter_scratch_bytes(const MeterPlan& pl, int ntracks, bool want_mask) {
+  const int64_t hs = pl.nhops + 4;
+  size_t b = 0;
+  b += align_up(sizeof(MeterPlan), 256);
+  b += align_up(sizeof(double) * (size_t)hs * ntracks * pl.nch, 256);
+  b += align_up(sizeof(double) * (size_t)ntracks * pl.nch, 256);
+  b += align_up(sizeof(double) * (size_t)(pl.nblocks > 0 ? pl.nblocks : 1) * ntracks, 256);
+  b += align_up(sizeof(GateOut) * (size_t)ntracks, 256);
+  if (want_mask) b += align_up((size_t)(pl.nblocks > 0 ? pl.nblocks : 1) * ntracks, 256);
+  return b;
+}
+
+void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void* scratch, MeterScratch* s) {
+  char* p = (char*)scratch;
+  s->hop_stride = pl.nhops + 4;
+  s->plan = (MeterPlan*)p; p += align_up(sizeof(MeterPlan), 256);
+  s->hopsums = (double*)p; s->hopsums_bytes = sizeof(double) * (size_t)s->hop_stride * ntracks * pl.nch; p += align_up(s->hopsums_bytes, 256);
+  s->peaks = (double*)p; p += align_up(sizeof(double) * (size_t)ntracks * pl.nch, 256);
+  s->blocks = (double*)p; p += align_up(sizeof(double) * (size_t)(pl.nblocks > 0 ? pl.nblocks : 1) * ntracks, 256);
+  s->gate = (GateOut*)p; p += align_up(sizeof(GateOut) * (size_t)ntracks, 256);
+  s->mask = want_mask ? (uint8_t*)p : nullptr;
+}
+
+int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream) {
+  hipLaunchKernelGGL(k_gate, dim3(ntracks), dim3(256), 0, stream, s.hopsums, s.hop_stride, s.peaks, s.plan, s.blocks, s.mask, s.gate);
+  WAM_HIP(hipGetLastError());
+  return WAM_OK;
+}
+
+int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, hipStream_t stream) {
+  WAM_HIP(hipMemcpyAsync(s.plan, &pl, sizeof(MeterPlan), hipMemcpyHostToDevice, stream));
+  WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_meter, dim3(ntracks * pl.nch), dim3(kThreads), 0, stream, in_dev, n, s.plan, s.hopsums, s.hop_stride, s.peaks);
+    WAM_HIP(hipGetLastError());
+  } else {
+    WAM_HIP(hipMemsetAsync(s.peaks, 0, sizeof(double) * (size_t)ntracks * pl.nch, stream));
+  }
+  return enqueue_gate(pl, ntracks, s, stream);
+}
+
+}  // namespace wam

@@ -1,0 +1,122 @@
+// meter.hpp - fused loudness / true-peak metering of a chunk held in registers.
+// Used by the stand-alone meter kernel and by every chain kernel that has to
+// measure what it just produced (stage 8 needs the loudness of its input, the
+// chain reports the loudness of its output).
+//
+// Reference: web/lib/dsp/lufs.js:17-82 (K-weighting shelf -> high-pass with an f32
+// store between and after, 400 ms blocks every 100 ms hop) and
+// web/lib/dsp/true-peak.js:46-71.  Per hop (100 ms) sums of squares are
+// accumulated in double; the gating kernel adds four hops per block.
+#pragma once
+#include "wam_device.hpp"
+
+namespace wam {
+
+struct MeterPlan {
+  Biquad shelf, hp;
+  int64_t hop;        // samples per 100 ms hop
+  int64_t nhops;      // complete hops in the track
+  int64_t nblocks;    // 400 ms blocks
+  int64_t block;      // samples per block (= 4 * hop, checked on the host)
+  int nch;
+  double fallback;
+  int too_short;      // duration < 0.4 s -> lufs = fallback (lufs.js:23-26)
+};
+
+struct MeterState {            // carried across tiles, per channel
+  double P1[4], P2[4];         // lane powers of the two filters
+  double S1a, S1b, S2a, S2b;   // tile carries of the two filters
+  float y1m1, y1m2;            // (thread 0 only matters) - unused placeholders
+  double peak;                 // running true peak of this thread
+  int64_t hop_idx, hop_off;    // hop index / offset of this thread's chunk start
+};
+
+__device__ __forceinline__ void meter_init(MeterState& m, const MeterPlan& pl, int64_t first_sample) {
+  biquad_lane_power(pl.shelf, lane_id(), m.P1);
+  biquad_lane_power(pl.hp, lane_id(), m.P2);
+  m.S1a = m.S1b = m.S2a = m.S2b = 0;
+  m.peak = 0;
+  const int64_t b = first_sample + (int64_t)threadIdx.x * C;
+  m.hop_idx = b / pl.hop;
+  m.hop_off = b - m.hop_idx * pl.hop;
+}
+
+// x[0..C) = this thread's samples (already rounded to f32 by the producing stage),
+// xp[0..3) = the three samples before the chunk (xp[2] = x[-1]); base = global
+// index of x[0]; n = track length.  lds: 16 doubles (two scan sites) + 4*kMaxK doubles.
+constexpr int kMeterLds = 16 + 4 * 4;
+__device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3], int64_t base, int64_t tile_base, int64_t n,
+                                            const MeterPlan& pl, MeterState& m, double* lds, double* hopsums) {
+  // ---- true peak (true-peak.js:53-65): history starts at zeros, evaluated for i >= 3
+  {
+    double y0 = xp[0], y1 = xp[1], y2 = xp[2];
+    double pk = m.peak;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const double y3 = x[k];
+      const int64_t i = base + k;
+      if (i >= 3 && i < n) pk = fmax(pk, true_peak4(y0, y1, y2, y3));
+      y0 = y1; y1 = y2; y2 = y3;
+    }
+    m.peak = pk;
+  }
+  // ---- K-weighting
+  double v[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (base + k < n) ? (double)x[k] : 0.0;
+  double s0, s1;
+  biquad_chunk(v, (base - 1 >= 0) ? (double)xp[2] : 0.0, (base - 2 >= 0) ? (double)xp[1] : 0.0, pl.shelf, m.P1, m.S1a, m.S1b, lds, s0, s1);
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
+  double t0, t1;
+  biquad_chunk(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2a, m.S2b, lds + 8, t0, t1);
+  // ---- per-hop sums of squares
+  const int64_t lim = pl.nhops * pl.hop;       // samples past the last complete hop never reach a block
+  double sA = 0, sB = 0;
+  const int64_t to_boundary = pl.hop - m.hop_off;   // samples of this chunk that belong to hop_idx
+#pragma unroll
+  for (int k = 0; k < C; k++) {
+    const double z = (double)f32r(v[k]);
+    const double zz = (base + k < lim) ? z * z : 0.0;
+    if (k < to_boundary) sA += zz; else sB += zz;
+  }
+  const int64_t h_first = tile_base / pl.hop;
+  int64_t last = tile_base + kTile - 1; if (last > lim - 1) last = lim - 1;
+  const int64_t h_last = last >= tile_base ? last / pl.hop : h_first - 1;
+  double* part = lds + 16;
+  for (int64_t h0 = h_first; h0 <= h_last; h0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t h = h0 + j;
+      if (h > h_last) break;
+      double c = 0;
+      if (h == m.hop_idx) c = sA; else if (h == m.hop_idx + 1) c = sB;
+      c = wave_sum_ordered(c);
+      if (lane_id() == 0) part[wave_id() * 4 + j] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      // thread (h & 3) owns hop h in every tile, so the read-modify-write below is same-thread ordered
+      const int j = (int)((threadIdx.x - h0) & 3);
+      if (h0 + j <= h_last) {
+        const double s = ((part[0 * 4 + j] + part[1 * 4 + j]) + part[2 * 4 + j]) + part[3 * 4 + j];
+        hopsums[h0 + j] += s;
+      }
+    }
+  }
+  // advance chunk position to the next tile
+  m.hop_off += kTile;
+  while (m.hop_off >= pl.hop) { m.hop_off -= pl.hop; m.hop_idx++; }
+}
+
+// Workgroup-wide final peak -> peaks[0]
+__device__ __forceinline__ void meter_finish(MeterState& m, double* lds, double* peak_out) {
+  const double w = wave_max(m.peak);
+  __syncthreads();
+  if (lane_id() == 0) lds[wave_id()] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) *peak_out = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+}
+
+}  // namespace wam

@@ -1,0 +1,34 @@
+// meter_host.hpp - host-visible declarations of the metering kernels' launchers.
+#pragma once
+#include "wam_common.hpp"
+#include "wam_plan.hpp"
+#include "meter.hpp"
+
+namespace wam {
+
+struct GateOut {
+  double mean2;      // mean of the blocks kept by both gates
+  double peak;       // linear true peak over the track's channels
+  int64_t c1, c2;    // blocks kept by the absolute gate / by both gates
+  int64_t nblocks;
+};
+
+struct MeterScratch {
+  MeterPlan* plan;
+  double* hopsums; size_t hopsums_bytes; int64_t hop_stride;
+  double* peaks;
+  double* blocks;
+  GateOut* gate;
+  uint8_t* mask;
+};
+
+int make_meter_plan(int nch, int64_t n, double sr, double fallback, MeterPlan* pl);
+size_t meter_scratch_bytes(const MeterPlan& pl, int ntracks, bool want_mask);
+void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void* scratch, MeterScratch* s);
+// zero hop sums, run k_meter over [ntracks][nch][n] and then k_gate
+int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, hipStream_t stream);
+int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream);
+double finish_lufs(const MeterPlan& pl, const GateOut& g);
+double finish_peak_db(const GateOut& g);
+
+}  // namespace wam

@@ -1,0 +1,45 @@
+// wam_common.hpp - host-side plumbing shared by the translation units of
+// libwam_hip.so: error reporting, device scratch, HIP call checking.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include "../../include/wam.h"
+
+namespace wam {
+
+void set_error(const char* fmt, ...);
+int ensure_device();                       // 0 or WAM_ERR_NO_DEVICE; binds the thread to the device chosen by wam_init
+
+#define WAM_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ::wam::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return WAM_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+// RAII device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t nbytes) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = nbytes;
+    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 16);
+    if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e)); return WAM_ERR_NOMEM; }
+    return WAM_OK;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace wam

@@ -1,0 +1,284 @@
+// wam_device.hpp - the "tile engine": device-side building blocks shared by every
+// kernel of the export chain and the meters (gfx950 only, wave = 64).
+//
+// Execution model (DESIGN.md "Kernels"): one 256-thread workgroup walks a
+// (track, channel-group) along time in tiles of TILE = 256 x C samples, carrying
+// all recurrence state from tile to tile in registers / LDS.  Inside a tile every
+// thread owns C consecutive samples (64 B of f32 per lane, loaded with 4
+// dwordx4), runs the recurrences on its chunk with zero state, the workgroup
+// combines the chunk summaries with an associative scan (wave-level shuffles,
+// then 4 wave aggregates through LDS) and each thread applies the correction for
+// its true start state.  LTI stages (biquads, one-poles) scan 2x2 / 1x1
+// state-transition powers; the branchy attack/release followers scan affine maps
+// under a decision policy and iterate the policy to its fixed point; the
+// release smoothers scan a hysteretic running maximum.
+//
+// Arithmetic follows the reference's convention: IEEE double for all scalar math,
+// one rounding to float where the reference stores into a Float32Array.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wam {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int C = 16;                  // samples per thread per tile
+constexpr int kTile = kThreads * C;    // 4096 samples
+
+// ---- host-prepared plans ---------------------------------------------------
+struct Biquad {            // y[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2] - a1 y[n-1] - a2 y[n-2]
+  double b0, b1, b2, a1, a2;
+  double h1[C], h2[C];     // response at n to unit start state (y[-1], y[-2]) = (1,0) / (0,1)
+  double Mp[7][4];         // M^(2^k), k = 0..6, M = transition of the state over one chunk (C samples)
+};
+struct OnePole {           // y[n] = c y[n-1] + u[n]
+  double c;
+  double cp[C];            // c^(n+1)
+  double Mp[7];            // (c^C)^(2^k)
+};
+
+// ---- small helpers ---------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ float f32r(double v) { return (float)v; }   // the Float32Array store
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_ordered(double v) {   // fixed tree: deterministic
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__device__ __forceinline__ void mat2_mul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] + a[1] * b[2]; o[1] = a[0] * b[1] + a[1] * b[3];
+  o[2] = a[2] * b[0] + a[3] * b[2]; o[3] = a[2] * b[1] + a[3] * b[3];
+}
+
+// M^lane from the power table (lane < 64)
+__device__ __forceinline__ void biquad_lane_power(const Biquad& q, int lane, double P[4]) {
+  P[0] = 1; P[1] = 0; P[2] = 0; P[3] = 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (lane & (1 << k)) { double t[4]; mat2_mul(q.Mp[k], P, t); P[0] = t[0]; P[1] = t[1]; P[2] = t[2]; P[3] = t[3]; }
+  }
+}
+__device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane) {
+  double p = 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) if (lane & (1 << k)) p *= q.Mp[k];
+  return p;
+}
+
+// ---- second-order scan -------------------------------------------------------
+// In: (e0,e1) = chunk end state for zero start state.  Out: (e0,e1) = true start
+// state of this thread's chunk.  (S0,S1) = tile carry (start state of thread 0),
+// updated to the carry of the next tile.  lds: 8 doubles private to this call site.
+__device__ __forceinline__ void scan2(double& e0, double& e1, const Biquad& q, const double P[4],
+                                      double& S0, double& S1, double* lds) {
+  const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int d = 1 << k;
+    const double t0 = __shfl_up(e0, d), t1 = __shfl_up(e1, d);
+    if (lane >= d) { e0 += q.Mp[k][0] * t0 + q.Mp[k][1] * t1; e1 += q.Mp[k][2] * t0 + q.Mp[k][3] * t1; }
+  }
+  if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
+  double x0 = __shfl_up(e0, 1), x1 = __shfl_up(e1, 1);
+  if (lane == 0) { x0 = 0; x1 = 0; }
+  __syncthreads();
+  double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    const double a0 = lds[2 * w], a1 = lds[2 * w + 1];
+    const double n0 = q.Mp[6][0] * w0 + q.Mp[6][1] * w1 + a0;
+    const double n1 = q.Mp[6][2] * w0 + q.Mp[6][3] * w1 + a1;
+    w0 = n0; w1 = n1;
+    if (w + 1 == wave) { my0 = w0; my1 = w1; }
+  }
+  S0 = w0; S1 = w1;
+  e0 = x0 + P[0] * my0 + P[1] * my1;
+  e1 = x1 + P[2] * my0 + P[3] * my1;
+}
+
+// One biquad stage over this thread's chunk, in place on x[] (double).
+// xm1/xm2 = the two inputs before the chunk.  s0/s1 returns the chunk's start
+// state (y[-1], y[-2]) = the previous thread's last two outputs in double: the
+// next cascaded stage takes its xm1/xm2 from them (after the f32 store rounding).
+__device__ __forceinline__ void biquad_chunk(double x[C], double xm1, double xm2, const Biquad& q, const double P[4],
+                                             double& S0, double& S1, double* lds, double& s0, double& s1) {
+  double p1 = 0, p2 = 0, i1 = xm1, i2 = xm2;
+#pragma unroll
+  for (int n = 0; n < C; n++) {
+    const double xi = x[n];
+    const double y = q.b0 * xi + q.b1 * i1 + q.b2 * i2 - q.a1 * p1 - q.a2 * p2;
+    i2 = i1; i1 = xi; p2 = p1; p1 = y;
+    x[n] = y;
+  }
+  s0 = p1; s1 = p2;
+  scan2(s0, s1, q, P, S0, S1, lds);
+#pragma unroll
+  for (int n = 0; n < C; n++) x[n] += q.h1[n] * s0 + q.h2[n] * s1;
+}
+
+// ---- first-order scan ----------------------------------------------------------
+__device__ __forceinline__ void scan1(double& e, const OnePole& q, double Pl, double& S, double* lds) {
+  const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int d = 1 << k;
+    const double t = __shfl_up(e, d);
+    if (lane >= d) e += q.Mp[k] * t;
+  }
+  if (lane == 63) lds[wave] = e;
+  double x = __shfl_up(e, 1);
+  if (lane == 0) x = 0;
+  __syncthreads();
+  double w = S, my = S;
+#pragma unroll
+  for (int k = 0; k < kWaves; k++) {
+    w = q.Mp[6] * w + lds[k];
+    if (k + 1 == wave) my = w;
+  }
+  S = w;
+  e = x + Pl * my;
+}
+// y[n] = c y[n-1] + u[n] over the chunk, in place on u[]; returns start state in s.
+__device__ __forceinline__ void onepole_chunk(double u[C], const OnePole& q, double Pl, double& S, double* lds, double& s) {
+  double p = 0;
+#pragma unroll
+  for (int n = 0; n < C; n++) { p = q.c * p + u[n]; u[n] = p; }
+  s = p;
+  scan1(s, q, Pl, S, lds);
+#pragma unroll
+  for (int n = 0; n < C; n++) u[n] += q.cp[n] * s;
+}
+
+// ---- affine scan (per-thread coefficients), used by the follower policy iteration ----
+// Each thread's chunk maps start value e to (al * e + be).  Returns this thread's
+// start value given the tile carry S; S advances to the next tile's carry.
+__device__ __forceinline__ double scan_affine(double al, double be, double& S, double* lds) {
+  const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int d = 1 << k;
+    const double ta = __shfl_up(al, d), tb = __shfl_up(be, d);
+    if (lane >= d) { be = al * tb + be; al = al * ta; }
+  }
+  if (lane == 63) { lds[2 * wave] = al; lds[2 * wave + 1] = be; }
+  double xa = __shfl_up(al, 1), xb = __shfl_up(be, 1);
+  if (lane == 0) { xa = 1; xb = 0; }
+  __syncthreads();
+  double w = S, my = S;
+#pragma unroll
+  for (int k = 0; k < kWaves; k++) {
+    w = lds[2 * k] * w + lds[2 * k + 1];
+    if (k + 1 == wave) my = w;
+  }
+  S = w;
+  return xa * my + xb;
+}
+
+// Branchy attack/release follower (dsp-worker.js:1308-1312, :345-349;
+// multiband-transient.js:219-230; dynamic-processor.js:33-43):
+//   e' = (a > e) ? A e + (1 - A) a : R e + (1 - R) a.
+// Policy iteration: guess each chunk's start value, run the chunk recording the
+// branch taken per sample (bitmask) and the affine map those branches compose to,
+// scan the maps for exact start values under that policy, repeat until no
+// thread's branch mask changes.  On exit start = the chunk's true start value.
+// a[] = rectified input of the chunk (>= 0).  Returns start; S = tile carry.
+__device__ __forceinline__ double follower_solve(const double a[C], double A, double R, double& S, double* lds) {
+  const double oA = 1 - A, oR = 1 - R;
+  double guess = S;
+  unsigned prev_mask = 0xFFFFFFFFu;   // impossible mask for C = 16
+  double start = S;
+  const double S_in = S;
+  for (int it = 0; it < 64; it++) {
+    double e = guess, al = 1, be = 0;
+    unsigned mask = 0;
+#pragma unroll
+    for (int n = 0; n < C; n++) {
+      const bool att = a[n] > e;
+      const double c = att ? A : R, oc = att ? oA : oR;
+      e = c * e + oc * a[n];
+      be = c * be + oc * a[n];
+      al = c * al;
+      mask |= (att ? 1u : 0u) << n;
+    }
+    double Sc = S_in;
+    start = scan_affine(al, be, Sc, lds);
+    const int changed = __syncthreads_or(mask != prev_mask);   // also fences the reuse of lds
+    S = Sc;
+    if (!changed) break;
+    prev_mask = mask;
+    guess = start;
+  }
+  return start;
+}
+
+// ---- loads / stores ----------------------------------------------------------
+// Load this thread's C samples of tile `tile` from p[0..n) (zeros past the end).
+__device__ __forceinline__ void load_chunk(const float* __restrict__ p, int64_t n, int64_t base, float v[C]) {
+  if (base + C <= n && ((reinterpret_cast<uintptr_t>(p + base) & 15) == 0)) {
+    const float4* q = reinterpret_cast<const float4*>(p + base);
+#pragma unroll
+    for (int k = 0; k < C / 4; k++) { const float4 t = q[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; k++) v[k] = (base + k < n) ? p[base + k] : 0.0f;
+  }
+}
+__device__ __forceinline__ void store_chunk(float* __restrict__ p, int64_t n, int64_t base, const float v[C]) {
+  if (base + C <= n && ((reinterpret_cast<uintptr_t>(p + base) & 15) == 0)) {
+    float4* q = reinterpret_cast<float4*>(p + base);
+#pragma unroll
+    for (int k = 0; k < C / 4; k++) q[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; k++) if (base + k < n) p[base + k] = v[k];
+  }
+}
+
+// Previous-thread context: every thread publishes its last K values, thread t
+// reads those of t-1; thread 0 reads the previous tile's thread 255 (zeros on
+// the first tile).  buf holds 2 x (kThreads + 1) x K floats (double-buffered by tile parity).
+template <int K>
+__device__ __forceinline__ void prev_context(const float last[K], float prev[K], float* buf, int parity, bool first_tile) {
+  float* cur = buf + parity * (kThreads + 1) * K;
+  const float* old = buf + (parity ^ 1) * (kThreads + 1) * K;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < K; k++) cur[(t + 1) * K + k] = last[k];
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) prev[k] = first_tile ? 0.0f : old[kThreads * K + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k++) prev[k] = cur[t * K + k];
+  }
+}
+
+// true-peak.js:13-38: max(|y2|, |p(1/4)|, |p(1/2)|, |p(3/4)|) of the Catmull-Rom segment y1..y2
+__device__ __forceinline__ double true_peak4(double y0, double y1, double y2, double y3) {
+  const double a0 = -0.5 * y0 + 1.5 * y1 - 1.5 * y2 + 0.5 * y3;
+  const double a1 = y0 - 2.5 * y1 + 2 * y2 - 0.5 * y3;
+  const double a2 = -0.5 * y0 + 0.5 * y2;
+  double pk = fabs(y2);
+  pk = fmax(pk, fabs(((a0 * 0.25 + a1) * 0.25 + a2) * 0.25 + y1));
+  pk = fmax(pk, fabs(((a0 * 0.5 + a1) * 0.5 + a2) * 0.5 + y1));
+  pk = fmax(pk, fabs(((a0 * 0.75 + a1) * 0.75 + a2) * 0.75 + y1));
+  return pk;
+}
+__device__ __forceinline__ double catmull_half(double y0, double y1, double y2, double y3) {   // utils.js:143-153 at t = 0.5
+  const double a0 = -0.5 * y0 + 1.5 * y1 - 1.5 * y2 + 0.5 * y3;
+  const double a1 = y0 - 2.5 * y1 + 2 * y2 - 0.5 * y3;
+  const double a2 = -0.5 * y0 + 0.5 * y2;
+  return a0 * 0.125 + a1 * 0.25 + a2 * 0.5 + y1;
+}
+
+}  // namespace wam
