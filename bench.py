@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - realtime factor of the MI355X mastering backend (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic 3-min stereo 48 kHz
+tracks already resident in HBM: the full export chain + LUFS/true-peak metering
+(`--workload chain`, BASELINE.json configs[2] sharded track-wise: `--tracks-per-gpu`
+tracks on each GPU, 128 x 8 GPUs = the 1,024-track batch) or metering only
+(`--workload meter`, configs[0]).  Tracks are independent, so ranks never exchange
+audio: weak scaling, no data-path collective; torch.distributed is
+used only for the barrier and the max-over-ranks reduction of the step time.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed
+on the launch stream through the library's profiling hooks) and `cpu_baseline`
+(the CPU oracle timed on a bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "web-audio-mastering_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402  (first: libwam_hip.so must bind to the same HIP runtime as torch)
+import torch.distributed as dist  # noqa: E402
+import wam  # noqa: E402
+
+SR = 48000
+SECONDS = 180
+NCH = 2
+N = SR * SECONDS
+
+# Settings of configs[1]/[2] (SURVEY.md 8d "C2"): UI defaults (web/index.html:178-295)
+# + glue compression + the 'aifix' EQ preset (web/lib/presets/eq.js:21).
+C2_SETTINGS = dict(wam.DEFAULT_SETTINGS, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1, eqHigh=2)
+SYNTH = dict(amp=1.6, dc=0.0, clickAmp=0.6)
+
+# algorithmic bytes per sample-channel of each kernel (DESIGN.md "Kernels")
+KERNEL_BYTES = {
+    "k_meter": 4,
+}
+
+
+class SynthOpts(C.Structure):
+    _fields_ = [("amp", C.c_double), ("dc", C.c_double), ("click_amp", C.c_double),
+                ("quiet_from", C.c_int64), ("quiet_to", C.c_int64), ("quiet_gain", C.c_double),
+                ("quiet2_from", C.c_int64), ("quiet2_to", C.c_int64), ("quiet2_gain", C.c_double)]
+
+
+def synth_dev(t, ntracks, idx0, opts, amp_step=0.0):
+    o = SynthOpts(opts.get("amp", 1.0), opts.get("dc", 0.0), opts.get("clickAmp", 0.0), -1, -1, 0.0, -1, -1, 0.0)
+    rc = wam.lib().wam_synth_dev(C.c_void_p(t.data_ptr()), C.c_int(ntracks), C.c_int(NCH), C.c_int64(t.shape[-1]), C.c_double(SR),
+                                 C.c_int(idx0), C.byref(o), C.c_double(amp_step), C.c_void_p(0))
+    if rc:
+        raise wam.WamError(wam.lib().wam_last_error().decode())
+
+
+def profile_read():
+    buf = C.create_string_buffer(1 << 16)
+    wam.lib().wam_profile_read(buf, C.c_size_t(len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def cpu_baseline(workload):
+    """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload."""
+    import oracle_lib as O
+    secs = 20 if workload == "chain" else 60
+    x = O.synth(0, NCH, secs * SR, SR, SYNTH)
+    t0 = time.perf_counter()
+    if workload == "chain":
+        O.render_chain(x, SR, C2_SETTINGS, "export")
+    else:
+        O.measure_lufs(x, SR)
+        O.true_peak_db(x)
+    dt = time.perf_counter() - t0
+    return {"value": secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port",
+            "sample": f"1 track x {secs} s stereo 48 kHz, same synthetic generator and settings, oracle/wam_oracle.c (C restatement of the reference JS), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tracks-per-gpu", type=int, default=128)
+    ap.add_argument("--workload", choices=["chain", "meter"], default="chain")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    wam.init(dev.index)
+
+    T = args.tracks_per_gpu
+    x = torch.empty((T, NCH, N), dtype=torch.float32, device=dev)
+    synth_dev(x, T, rank * T, SYNTH, amp_step=0.3 / max(T, 1))      # distinct seed per track, levels 1.6 .. 1.9
+    y = torch.empty_like(x) if args.workload == "chain" else None
+    torch.cuda.synchronize()
+
+    def step():
+        if args.workload == "chain":
+            return wam.batch_render_dev(x.data_ptr(), y.data_ptr(), T, NCH, N, SR, C2_SETTINGS, "export")
+        return wam.batch_meter_dev(x.data_ptr(), T, NCH, N, SR)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    wam.lib().wam_profile_enable(1)
+    profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = profile_read()
+    wam.lib().wam_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        audio_s = world * T * SECONDS * args.steps
+        ms_per_step = dt / args.steps * 1e3
+        # dominant kernel by total device time
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
+        roofline = None
+        if dom:
+            name, (cnt, total_ms) = dom
+            launches_per_step = cnt / args.steps
+            avg_ms = total_ms / cnt
+            bpsc = KERNEL_BYTES.get(name)
+            if bpsc is not None:
+                alg_bytes = bpsc * T * NCH * N / max(1.0, launches_per_step) if launches_per_step >= 1 else bpsc * T * NCH * N
+                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                            "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+                            "algorithmic_bytes_per_launch": alg_bytes}
+            else:
+                roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                            "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}
+        kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        kernel_ms_per_step = sum(v[1] for v in prof.values()) / args.steps
+        chain_bytes = (16 if args.workload == "chain" else 4) * T * NCH * N
+        out = {
+            "metric": "x realtime (audio-s/s) full master chain+LUFS" if args.workload == "chain" else "x realtime (audio-s/s) LUFS+true-peak meter",
+            "value": audio_s / dt, "unit": "x realtime (audio-s/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[2] shard: {T} tracks/GPU x 3-min stereo 48 kHz, full export chain "
+                                    "(input gain, de-harsh, exciter, tape warmth, punch, 30 Hz HPF + 18 kHz LPF, 5-band EQ 'aifix', glue comp, "
+                                    "mono-bass M/S, -14 LUFS normalise, soft clip, TP limiter) + LUFS/true-peak of the result"
+                                    if args.workload == "chain" else
+                                    f"BASELINE configs[0] batched: {T} tracks/GPU x 3-min stereo 48 kHz, integrated LUFS + true peak"),
+                       "tracks_per_gpu": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
+                       "settings": C2_SETTINGS if args.workload == "chain" else None, "parallelism": f"track-sharded x{world}, no collective"},
+            "roofline": roofline,
+            "chain_hbm_frac": (chain_bytes / (kernel_ms_per_step * 1e-3) / 8e12) if kernel_ms_per_step > 0 else None,
+            "kernel_ms_per_step": kernel_ms_per_step,
+            "kernels": kernels,
+        }
+        if args.workload == "chain":
+            out["sample_result"] = {"lufs": res[0].lufs, "true_peak_db": res[0].true_peak_db, "lufs_in": res[0].lufs_in, "gain_db": res[0].gain_db}
+        else:
+            out["sample_result"] = {"lufs": float(res[0][0]), "true_peak_db": float(res[1][0])}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

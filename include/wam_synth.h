@@ -1,0 +1,37 @@
+/*
+ * wam_synth.h - measurement utilities of libwam_hip.so.  None of these has a
+ * counterpart in the reference: they exist so that bench.py and the full-size
+ * GPU tests can create multi-GB synthetic inputs on the device and read
+ * per-kernel timings.  The generator ("synth v1") is bit-identical to
+ * tests/golden/synth.mjs (the inputs of the golden vectors) and oracle/wam_synth.c.
+ */
+#ifndef WAM_SYNTH_H
+#define WAM_SYNTH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wam_synth_opts {
+  double amp, dc, click_amp;
+  int64_t quiet_from, quiet_to; double quiet_gain;
+  int64_t quiet2_from, quiet2_to; double quiet2_gain;
+} wam_synth_opts;
+
+/* out_dev: device [ntracks][nch][n] float32.  Track t uses seed idx0 + t and
+ * amplitude amp + t * amp_step. */
+int wam_synth_dev(float* out_dev, int ntracks, int nch, int64_t n, double sample_rate, int idx0,
+                  const wam_synth_opts* opts, double amp_step, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream, around every
+ * kernel the library launches while enabled.  wam_profile_read() synchronises,
+ * writes one line per kernel name "name count total_ms\n" into buf and clears
+ * the log.  Returns the number of bytes written (excluding the NUL). */
+int wam_profile_enable(int on);
+int wam_profile_read(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -2,6 +2,9 @@
 // <-> device staging, and the calls into the kernel launchers.  There is no CPU
 // path here: every compute entry point needs a HIP device.
 #include "meter_host.hpp"
+#include "../../include/wam_synth.h"
+#include <map>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -15,6 +18,26 @@ void set_error(const char* fmt, ...) {
   char buf[1024];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
   g_err = buf;
+}
+
+// ---- per-kernel timing ------------------------------------------------------
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfEntry> g_prof;
+
+void prof_begin(const char* name, hipStream_t s) {
+  if (!g_prof_on) return;
+  ProfEntry e; e.name = name;
+  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+  (void)hipEventRecord(e.a, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(e);
+}
+void prof_end(hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, s);
 }
 
 int ensure_device() {
@@ -74,6 +97,26 @@ extern "C" {
 
 const char* wam_last_error(void) { return g_err.c_str(); }
 const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
+
+int wam_profile_enable(int on) { g_prof_on = on != 0; return WAM_OK; }
+
+int wam_profile_read(char* buf, size_t cap) {
+  (void)hipDeviceSynchronize();
+  std::map<std::string, std::pair<int, double>> agg;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { auto& a = agg[e.name]; a.first++; a.second += ms; }
+      (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    g_prof.clear();
+  }
+  std::string out;
+  for (auto& kv : agg) { char line[256]; snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second); out += line; }
+  if (buf && cap > 0) { size_t m = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), m); buf[m] = 0; return (int)m; }
+  return 0;
+}
 
 int wam_device_count(int* count) {
   int n = 0;

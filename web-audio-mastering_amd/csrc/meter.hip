@@ -144,8 +144,7 @@ void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void*
 }
 
 int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream) {
-  hipLaunchKernelGGL(k_gate, dim3(ntracks), dim3(256), 0, stream, s.hopsums, s.hop_stride, s.peaks, s.plan, s.blocks, s.mask, s.gate);
-  WAM_HIP(hipGetLastError());
+  WAM_LAUNCH("k_gate", k_gate, dim3(ntracks), dim3(256), stream, s.hopsums, s.hop_stride, s.peaks, s.plan, s.blocks, s.mask, s.gate);
   return WAM_OK;
 }
 
@@ -153,8 +152,7 @@ int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t
   WAM_HIP(hipMemcpyAsync(s.plan, &pl, sizeof(MeterPlan), hipMemcpyHostToDevice, stream));
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
   if (n > 0) {
-    hipLaunchKernelGGL(k_meter, dim3(ntracks * pl.nch), dim3(kThreads), 0, stream, in_dev, n, s.plan, s.hopsums, s.hop_stride, s.peaks);
-    WAM_HIP(hipGetLastError());
+    WAM_LAUNCH("k_meter", k_meter, dim3(ntracks * pl.nch), dim3(kThreads), stream, in_dev, n, s.plan, s.hopsums, s.hop_stride, s.peaks);
   } else {
     WAM_HIP(hipMemsetAsync(s.peaks, 0, sizeof(double) * (size_t)ntracks * pl.nch, stream));
   }

@@ -40,6 +40,17 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// per-kernel timing hooks (include/wam_synth.h: wam_profile_enable / wam_profile_read)
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+#define WAM_LAUNCH(name, kern, grid, block, stream, ...)                 \
+  do {                                                                   \
+    ::wam::prof_begin(name, stream);                                     \
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);       \
+    ::wam::prof_end(stream);                                             \
+    WAM_HIP(hipGetLastError());                                          \
+  } while (0)
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace wam
