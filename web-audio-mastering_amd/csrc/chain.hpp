@@ -1,0 +1,41 @@
+// chain.hpp - plan (all host-computed constants) and launcher declarations for the
+// export chain, web/workers/dsp-worker.js:1468-1667.
+#pragma once
+#include "meter_host.hpp"
+
+namespace wam {
+
+struct FrontPlan {             // stages 5, 6, 7, 7.5 (dsp-worker.js:1556-1599)
+  int do_hpf, do_lpf, n_eq, do_glue, do_stereo, do_meter;
+  Biquad hpf30;                // final-filters.js:96-131
+  OnePole lpf18; double lpf_alpha;
+  Biquad eq[6];                // dsp-worker.js:1236-1264 (spec-defined)
+  double glue_thr, glue_k, glue_A, glue_R;   // dsp-worker.js:1296-1298; k = 1 - 1/ratio
+  Biquad side_hp; double side_gain; int bass_mono;   // dsp-worker.js:1160-1187
+};
+
+struct ClipPlan {              // stage 9, soft-clipper.js:165-294
+  double ceil_lin, thr_lin, range_div, range, drive, rc, rcC;
+  int L;
+};
+
+struct LimiterPlan {           // stage 10, dsp-worker.js:286-452
+  double ceil_lin, knee_db, knee_start, rc, rcC, pa, pr;
+  int L, W, preserve;
+};
+
+struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.js, multiband-transient.js
+  Biquad exc_hp;
+  Biquad w_lp1, w_hp1, w_lp2, w_hp2;
+  Biquad p_lp1, p_hp1, p_lp2, p_hp2;
+  double w_drive[3], w_bias[3], w_mix[3], w_bo[3], w_mk[3];
+  int64_t w_ws, w_nw;          // bypass-envelope window (samples) and count
+  double pf_A[3], pf_R[3], ps_A[3], ps_R[3], p_tg[3], p_sg[3];
+  OnePole p_smooth;
+};
+
+// ---- launchers (chain_*.hip).  All buffers are device pointers, layout [ntracks][nch][n]. ----
+int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
+                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s);
+
+}  // namespace wam

@@ -1,0 +1,117 @@
+// chain_api.hip - host side of the export chain: plan builders (reference formulas in
+// double with the host libm), the single-stage C ABI entry points and the
+// RENDER_FULL_CHAIN driver (dsp-worker.js:1468-1667) that strings the kernels together.
+#include "chain.hpp"
+#include <cmath>
+#include <cstring>
+
+namespace wam {
+
+// ---------------------------------------------------------------------------- plans
+void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains /*5 or NULL*/, int cut_mud,
+                     int do_glue, double glue_thr_db, double glue_ratio, double glue_attack, double glue_release,
+                     int do_stereo, double width, int bass_mono, double bass_freq, int do_meter, FrontPlan* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->do_hpf = do_hpf; p->do_lpf = do_lpf; p->do_glue = do_glue; p->do_stereo = do_stereo; p->do_meter = do_meter;
+  p->hpf30 = rbj_pass(sr, 30, 0.707, true);                       // final-filters.js:100-102
+  {
+    const double rc = 1 / (2 * M_PI * 18000);                     // final-filters.js:69-71
+    const double dt = 1 / sr;
+    const double alpha = dt / (rc + dt);
+    p->lpf_alpha = alpha;
+    p->lpf18 = make_onepole(1 - alpha);
+  }
+  static const int types[5] = {0, 1, 1, 1, 2};
+  static const double freqs[5] = {80, 250, 1000, 4000, 12000};   // dsp-worker.js:1236-1259
+  p->n_eq = 0;
+  for (int b = 0; b < 6; b++) p->eq[b] = identity_biquad();
+  if (eq_gains) for (int b = 0; b < 5; b++) if (eq_gains[b] != 0 && eq_gains[b] == eq_gains[b]) p->eq[p->n_eq++] = webaudio_biquad(types[b], sr, freqs[b], eq_gains[b], 1.0);
+  if (cut_mud) p->eq[p->n_eq++] = webaudio_biquad(1, sr, 250, -3.0, 1.5);                         // dsp-worker.js:1262-1264
+  p->glue_thr = std::pow(10, glue_thr_db / 20);                    // dsp-worker.js:1296-1298
+  p->glue_k = 1 - 1 / glue_ratio;
+  p->glue_A = std::exp(-1 / (glue_attack * sr));
+  p->glue_R = std::exp(-1 / (glue_release * sr));
+  p->side_hp = (bass_mono && bass_freq > 0) ? stereo_side_hp(sr, bass_freq) : identity_biquad();
+  p->bass_mono = (bass_mono && bass_freq > 0) ? 1 : 0;
+  p->side_gain = std::pow(10, 0 / 20.0) * width;                   // dsp-worker.js:1187
+}
+
+// ---------------------------------------------------------------------------- staging helpers
+struct Staged {            // host planar channels <-> contiguous device [nch][n]
+  DevBuf in, out;
+  int nch = 0; int64_t n = 0;
+  int up(const float* const* ch, int nch_, int64_t n_, hipStream_t s) {
+    nch = nch_; n = n_;
+    const size_t bytes = sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1);
+    int rc = in.alloc(bytes); if (rc) return rc;
+    rc = out.alloc(bytes); if (rc) return rc;
+    for (int c = 0; c < nch && n > 0; c++)
+      WAM_HIP(hipMemcpyAsync(in.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+    return WAM_OK;
+  }
+  int down(const float* src, float* const* o, hipStream_t s) {
+    for (int c = 0; c < nch && n > 0; c++)
+      WAM_HIP(hipMemcpyAsync(o[c], src + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    WAM_HIP(hipStreamSynchronize(s));
+    return WAM_OK;
+  }
+};
+
+static int check_io(const float* const* ch, int nch, int64_t n, float* const* out) {
+  if (!ch || !out || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
+  for (int c = 0; c < nch; c++) if ((!ch[c] || !out[c]) && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
+
+template <class T>
+static int upload_plan(const T& host, DevBuf& buf, hipStream_t s) {
+  int rc = buf.alloc(sizeof(T)); if (rc) return rc;
+  WAM_HIP(hipMemcpyAsync(buf.p, &host, sizeof(T), hipMemcpyHostToDevice, s));
+  return WAM_OK;
+}
+
+static int run_front_only(const float* const* ch, int nch, int64_t n, double sr, const FrontPlan& fp, float* const* out) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  DevBuf plan; rc = upload_plan(fp, plan, nullptr); if (rc) return rc;
+  rc = enqueue_front(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<FrontPlan>(), nullptr, nullptr, 0, nullptr, 1.0, nullptr);
+  if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
+}
+
+}  // namespace wam
+
+using namespace wam;
+
+extern "C" {
+
+int wam_final_filters(const float* const* ch, int nch, int64_t n, double sr, int highpass, int lowpass, float* const* out) {
+  FrontPlan fp;
+  make_front_plan(sr, highpass != 0, lowpass != 0, nullptr, 0, 0, -18, 3, 0.02, 0.25, 0, 1.0, 0, 200, 0, &fp);
+  return run_front_only(ch, nch, n, sr, fp, out);
+}
+
+int wam_parametric_eq(const float* const* ch, int nch, int64_t n, double sr, const double gains_db[5], int cut_mud, float* const* out) {
+  if (!gains_db) { set_error("gains_db is NULL"); return WAM_ERR_INVALID; }
+  FrontPlan fp;
+  make_front_plan(sr, 0, 0, gains_db, cut_mud, 0, -18, 3, 0.02, 0.25, 0, 1.0, 0, 200, 0, &fp);
+  return run_front_only(ch, nch, n, sr, fp, out);
+}
+
+int wam_glue_compressor(const float* const* ch, int nch, int64_t n, double sr, double threshold_db, double ratio, double attack_s,
+                        double release_s, float* const* out) {
+  if (!(ratio > 0) || !(attack_s > 0) || !(release_s > 0)) { set_error("invalid compressor parameters"); return WAM_ERR_INVALID; }
+  FrontPlan fp;
+  make_front_plan(sr, 0, 0, nullptr, 0, 1, threshold_db, ratio, attack_s, release_s, 0, 1.0, 0, 200, 0, &fp);
+  return run_front_only(ch, nch, n, sr, fp, out);
+}
+
+int wam_stereo(const float* const* ch, int64_t n, double sr, double width, int bass_mono, double bass_freq, float* const* out) {
+  FrontPlan fp;
+  make_front_plan(sr, 0, 0, nullptr, 0, 0, -18, 3, 0.02, 0.25, 1, width, bass_mono, bass_freq, 0, &fp);
+  return run_front_only(ch, 2, n, sr, fp, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// chain_front.hip - stages 5..7.5 of the export chain fused into one pass, plus the
+// loudness / true-peak measurement of the result that stage 8 needs:
+//   final filters (30 Hz biquad HPF, 18 kHz one-pole LPF)   final-filters.js:96-131
+//   5-band EQ + Cut Mud (spec-defined biquads)                dsp-worker.js:1222-1267
+//   glue compressor, linked side-chain                        dsp-worker.js:1272-1343
+//   M/S width + mono bass                                     dsp-worker.js:1122-1217
+// One workgroup per track (both channels: the side-chain and the M/S matrix link them).
+// Algorithmic traffic: 4 B read + 4 B written per sample-channel.
+#include "chain.hpp"
+
+namespace wam {
+
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                    const FrontPlan* __restrict__ fp, const MeterPlan* __restrict__ mp,
+                                                    double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
+                                                    double pre_gain) {
+  __shared__ double lds_scan[kSlotDoubles];
+  __shared__ double lds_meter[NCH][kMeterLds];
+  __shared__ float ctx[NCH * 9 + 1][kCtxFloats];   // per channel: hpf, 6 eq, lpf->eq, meter; + side
+  __shared__ float bc[NCH];
+  const FrontPlan& P = *fp;
+  const int64_t trk = blockIdx.x;
+  const float* x[NCH]; float* y[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) { x[c] = in + (trk * NCH + c) * n; y[c] = out + (trk * NCH + c) * n; }
+  const int lane = lane_id();
+  LdsSlots slots(lds_scan);
+
+  // carried state
+  double Phpf[4], Peq[6][4], Pside[4], Plpf;
+  biquad_lane_power(P.hpf30, lane, Phpf);
+#pragma unroll
+  for (int b = 0; b < 6; b++) if (b < P.n_eq) biquad_lane_power(P.eq[b], lane, Peq[b]);
+  biquad_lane_power(P.side_hp, lane, Pside);
+  Plpf = onepole_lane_power(P.lpf18, lane);
+  double Shpf[NCH][2] = {}, Slpf[NCH] = {}, Seq[NCH][6][2] = {}, Sside[2] = {0, 0}, Senv = 0;
+  MeterState ms[NCH];
+  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_init(ms[c], *mp, 0);
+
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    const int par = (int)(t & 1);
+    float w[NCH][C];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v[C];
+      load_chunk(x[c], n, base, v);
+      if (pre_gain != 1.0) {
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * pre_gain);
+      }
+      double d[C];
+#pragma unroll
+      for (int k = 0; k < C; k++) d[k] = v[k];
+      double nb1 = 0, nb2 = 0;     // the two inputs before the chunk, for the next biquad's FIR part
+      bool have_nb = false;
+      if (P.do_hpf) {
+        const float last[2] = { v[C - 2], v[C - 1] };
+        float pv[2];
+        prev_ctx<2>(last, pv, ctx[c * 9 + 0], par, t == 0);
+        double s0, s1;
+        biquad_chunk(d, pv[1], pv[0], P.hpf30, Phpf, Shpf[c][0], Shpf[c][1], slots.next(), s0, s1);
+#pragma unroll
+        for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
+        nb1 = (double)f32r(s0); nb2 = (double)f32r(s1); have_nb = true;
+      }
+      if (P.do_lpf) {
+        // applyOnePoleLP (final-filters.js:68-78): y starts at data[0]
+        if (t == 0) {
+          if (threadIdx.x == 0) bc[c] = f32r(d[0]);
+          __syncthreads();
+          const float f0 = bc[c];
+          Slpf[c] = (f0 == f0) ? (double)f0 : 0.0;
+        }
+        double u[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) u[k] = P.lpf_alpha * d[k];
+        double s;
+        onepole_chunk(u, P.lpf18, Plpf, Slpf[c], slots.next(), s);
+#pragma unroll
+        for (int k = 0; k < C; k++) d[k] = (double)f32r(u[k]);
+        have_nb = false;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        if (b >= P.n_eq) break;
+        if (!have_nb) {
+          const float last[2] = { f32r(d[C - 2]), f32r(d[C - 1]) };
+          float pv[2];
+          prev_ctx<2>(last, pv, ctx[c * 9 + 1 + b], par, t == 0);
+          nb1 = pv[1]; nb2 = pv[0];
+        }
+        double s0, s1;
+        biquad_chunk(d, nb1, nb2, P.eq[b], Peq[b], Seq[c][b][0], Seq[c][b][1], slots.next(), s0, s1);
+#pragma unroll
+        for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
+        nb1 = (double)f32r(s0); nb2 = (double)f32r(s1); have_nb = true;
+      }
+#pragma unroll
+      for (int k = 0; k < C; k++) w[c][k] = f32r(d[k]);
+    }
+
+    if (P.do_glue) {
+      // linked side-chain (dsp-worker.js:1287-1293), follower :1304-1312, gain :1318-1324
+      double a[C];
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        float sc;
+        if (NCH >= 2) sc = f32r(((double)w[0][k] + (double)w[NCH - 1][k]) * 0.5); else sc = w[0][k];
+        a[k] = fabs((double)sc);
+        if (base + k >= n) a[k] = 0;
+      }
+      double e = follower_solve(a, P.glue_A, P.glue_R, Senv, slots.next());
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        e = follower_step(e, a[k], P.glue_A, P.glue_R);
+        float g = 1.0f;
+        if (e > P.glue_thr) {
+          // 10^(-(20 log10(e/thr)) (1 - 1/ratio) / 20) = (e/thr)^-(1 - 1/ratio); stored to a Float32Array by the reference
+          g = exp2f(-(float)P.glue_k * log2f((float)(e / P.glue_thr)));
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) w[c][k] = f32r((double)w[c][k] * (double)g);
+      }
+    }
+
+    if (NCH == 2 && P.do_stereo) {
+      float mid[C], side[C];
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        mid[k] = f32r(((double)w[0][k] + (double)w[1][k]) * 0.5);
+        side[k] = f32r(((double)w[0][k] - (double)w[1][k]) * 0.5);
+      }
+      if (P.bass_mono) {
+        const float last[2] = { side[C - 2], side[C - 1] };
+        float pv[2];
+        prev_ctx<2>(last, pv, ctx[NCH * 9], par, t == 0);
+        double d[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) d[k] = side[k];
+        double s0, s1;
+        biquad_chunk(d, pv[1], pv[0], P.side_hp, Pside, Sside[0], Sside[1], slots.next(), s0, s1);
+#pragma unroll
+        for (int k = 0; k < C; k++) side[k] = f32r(d[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const float pm = f32r((double)mid[k] * 1.0);
+        const float ps = f32r((double)side[k] * P.side_gain);
+        w[0][k] = f32r((double)pm + (double)ps);
+        w[1][k] = f32r((double)pm - (double)ps);
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      store_chunk(y[c], n, base, w[c]);
+      if (P.do_meter) {
+        const float last[3] = { w[c][C - 3], w[c][C - 2], w[c][C - 1] };
+        float xp[3];
+        prev_ctx<3>(last, xp, ctx[c * 9 + 8], par, t == 0);
+        meter_chunk(w[c], xp, base, tile_base, n, *mp, ms[c], lds_meter[c], hopsums + (trk * NCH + c) * hop_stride);
+      }
+    }
+  }
+  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_finish(ms[c], lds_meter[c], peaks + trk * NCH + c);
+}
+
+int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
+                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s) {
+  if (n <= 0) return WAM_OK;
+  if (nch == 2) WAM_LAUNCH("k_front", k_front<2>, dim3(ntracks), dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain);
+  else WAM_LAUNCH("k_front", k_front<1>, dim3(ntracks), dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain);
+  return WAM_OK;
+}
+
+}  // namespace wam

@@ -183,23 +183,42 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
   return xa * my + xb;
 }
 
+// ---- piecewise-affine recurrences: policy iteration ---------------------------------
+// A recurrence e[n] = f_n(e[n-1]) whose step is piecewise affine (attack/release
+// followers, release smoothers with resets).  Each thread runs its chunk from a
+// guessed start value with a functor
+//     run(start, al, be, mask)
+// that returns the affine map (al, be) its chunk composes to UNDER THE BRANCHES IT
+// TOOK and a bitmask of those branches.  The maps are scanned for the start values
+// that policy implies; the loop repeats until no thread's mask changes, at which
+// point start values, branches and maps are mutually consistent = the sequential
+// solution.  Returns this thread's start value; S = tile carry in/out.
+template <class Run>
+__device__ __forceinline__ double solve_piecewise(Run run, double guess, double& S, double* lds, int max_iter = 260) {
+  const double S_in = S;
+  unsigned prev_mask = 0xFFFFFFFFu;
+  double start = guess;
+  for (int it = 0; it < max_iter; it++) {
+    double al, be; unsigned mask;
+    run(start, al, be, mask);
+    double Sc = S_in;
+    const double ns = scan_affine(al, be, Sc, lds);
+    const int changed = __syncthreads_or((mask != prev_mask) || (it == 0));   // also fences the reuse of lds
+    S = Sc;
+    if (!changed) break;
+    prev_mask = mask;
+    start = ns;
+  }
+  return start;
+}
+
 // Branchy attack/release follower (dsp-worker.js:1308-1312, :345-349;
-// multiband-transient.js:219-230; dynamic-processor.js:33-43):
-//   e' = (a > e) ? A e + (1 - A) a : R e + (1 - R) a.
-// Policy iteration: guess each chunk's start value, run the chunk recording the
-// branch taken per sample (bitmask) and the affine map those branches compose to,
-// scan the maps for exact start values under that policy, repeat until no
-// thread's branch mask changes.  On exit start = the chunk's true start value.
-// a[] = rectified input of the chunk (>= 0).  Returns start; S = tile carry.
+// multiband-transient.js:219-230): e' = (a > e) ? A e + (1-A) a : R e + (1-R) a.
+// a[] = rectified input of the chunk.  Returns the chunk's true start value.
 __device__ __forceinline__ double follower_solve(const double a[C], double A, double R, double& S, double* lds) {
   const double oA = 1 - A, oR = 1 - R;
-  double guess = S;
-  unsigned prev_mask = 0xFFFFFFFFu;   // impossible mask for C = 16
-  double start = S;
-  const double S_in = S;
-  for (int it = 0; it < 64; it++) {
-    double e = guess, al = 1, be = 0;
-    unsigned mask = 0;
+  auto run = [&](double e, double& al, double& be, unsigned& mask) {
+    al = 1; be = 0; mask = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const bool att = a[n] > e;
@@ -209,15 +228,42 @@ __device__ __forceinline__ double follower_solve(const double a[C], double A, do
       al = c * al;
       mask |= (att ? 1u : 0u) << n;
     }
-    double Sc = S_in;
-    start = scan_affine(al, be, Sc, lds);
-    const int changed = __syncthreads_or(mask != prev_mask);   // also fences the reuse of lds
-    S = Sc;
-    if (!changed) break;
-    prev_mask = mask;
-    guess = start;
+  };
+  return solve_piecewise(run, S, S, lds);
+}
+// one follower step, for the final pass that materialises the envelope
+__device__ __forceinline__ double follower_step(double e, double a, double A, double R) {
+  return (a > e) ? A * e + (1 - A) * a : R * e + (1 - R) * a;
+}
+
+// Release smoother with resets (dsp-worker.js:416-425, soft-clipper.js:222-231):
+//   cur' = (g < cur) ? g : min(rc cur + (1 - rc), 1).
+// g[] = this chunk's raw gains (f32 values).  rcC = rc^C.  Returns the chunk's start value.
+__device__ __forceinline__ double release_solve(const float g[C], double rc, double rcC, double& S, double* lds) {
+  const double orc = 1 - rc;
+  auto run = [&](double cur, double& al, double& be, unsigned& mask) {
+    mask = 0;
+#pragma unroll
+    for (int n = 0; n < C; n++) {
+      const double gn = (double)g[n];
+      if (gn < cur) { cur = gn; mask |= 1u << n; }
+      else { cur = rc * cur + orc * 1.0; cur = fmin(cur, 1.0); }
+    }
+    if (mask) { al = 0; be = cur; } else { al = rcC; be = 1 - rcC; }
+  };
+  // first guess: pure release from the carry (exact when the tile has no reset)
+  double guess = S;
+  {
+    // rc^(C*t) for this thread = rcC^t, by square-and-multiply on the fly
+    double p = 1, b = rcC; int t = threadIdx.x;
+    while (t) { if (t & 1) p *= b; b *= b; t >>= 1; }
+    guess = 1 - p * (1 - S);
   }
-  return start;
+  return solve_piecewise(run, guess, S, lds);
+}
+__device__ __forceinline__ double release_step(double cur, double g, double rc) {
+  if (g < cur) return g;
+  return fmin(rc * cur + (1 - rc) * 1.0, 1.0);
 }
 
 // ---- loads / stores ----------------------------------------------------------
@@ -263,6 +309,33 @@ __device__ __forceinline__ void prev_context(const float last[K], float prev[K],
   }
 }
 
+// Same exchange for kernels with several call sites per tile: neighbours inside a
+// wave come by shuffle, wave edges and the tile carry through a site-private LDS
+// record of 2 x kWaves x K floats (double-buffered by tile parity: one barrier per call).
+template <int K>
+__device__ __forceinline__ void prev_ctx(const float last[K], float prev[K], float* site, int parity, bool first_tile) {
+  const int lane = lane_id(), wave = wave_id();
+  float* cur = site + parity * kWaves * K;
+  const float* old = site + (parity ^ 1) * kWaves * K;
+#pragma unroll
+  for (int k = 0; k < K; k++) prev[k] = __shfl_up(last[k], 1);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < K; k++) cur[wave * K + k] = last[k];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) prev[k] = first_tile ? 0.0f : old[(kWaves - 1) * K + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) prev[k] = cur[(wave - 1) * K + k];
+    }
+  }
+}
+constexpr int kCtxFloats = 2 * kWaves * 3;   // per site, K <= 3
+
 // true-peak.js:13-38: max(|y2|, |p(1/4)|, |p(1/2)|, |p(3/4)|) of the Catmull-Rom segment y1..y2
 __device__ __forceinline__ double true_peak4(double y0, double y1, double y2, double y3) {
   const double a0 = -0.5 * y0 + 1.5 * y1 - 1.5 * y2 + 0.5 * y3;
@@ -280,5 +353,14 @@ __device__ __forceinline__ double catmull_half(double y0, double y1, double y2, 
   const double a2 = -0.5 * y0 + 0.5 * y2;
   return a0 * 0.125 + a1 * 0.25 + a2 * 0.5 + y1;
 }
+
+// Two alternating LDS scratch slots for consecutive scans: scan k+2 may overwrite the
+// slot of scan k because every thread passed scan k+1's barrier after reading it.
+struct LdsSlots {
+  double* base; int flip;
+  __device__ __forceinline__ explicit LdsSlots(double* b) : base(b), flip(0) {}
+  __device__ __forceinline__ double* next() { flip ^= 1; return base + flip * 16; }
+};
+constexpr int kSlotDoubles = 32;
 
 }  // namespace wam
