@@ -38,4 +38,15 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s);
 
+int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev,
+                      const double* gains_dev, hipStream_t s);
+int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev,
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s);
+
+void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains, int cut_mud,
+                     int do_glue, double glue_thr_db, double glue_ratio, double glue_attack, double glue_release,
+                     int do_stereo, double width, int bass_mono, double bass_freq, int do_meter, FrontPlan* p);
+int make_clip_plan(double sr, double ceiling_db, double lookahead_ms, double release_ms, double drive, ClipPlan* p);
+int make_limiter_plan(double sr, double ceil_lin, double lookahead_ms, double release_ms, double knee_db, int preserve, LimiterPlan* p);
+
 }  // namespace wam

@@ -36,6 +36,39 @@ void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains /
   p->side_gain = std::pow(10, 0 / 20.0) * width;                   // dsp-worker.js:1187
 }
 
+int make_clip_plan(double sr, double ceiling_db, double lookahead_ms, double release_ms, double drive, ClipPlan* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->ceil_lin = std::pow(10, ceiling_db / 20);                     // soft-clipper.js:177-180
+  p->thr_lin = std::pow(10, (ceiling_db + 3) / 20);
+  p->L = (int)std::floor(sr * lookahead_ms / 1000);
+  p->rc = std::exp(-1 / (release_ms * sr / 1000));
+  p->rcC = std::pow(p->rc, (double)C);
+  p->range = p->ceil_lin - p->thr_lin;                             // soft-clipper.js:203-204
+  p->range_div = std::fmax(p->range, 0.001);
+  p->drive = drive;
+  if (p->L < 0 || p->L > 256) { set_error("soft-clip lookahead of %d samples is outside 0..256", p->L); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
+
+int make_limiter_plan(double sr, double ceil_lin, double lookahead_ms, double release_ms, double knee_db, int preserve, LimiterPlan* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->ceil_lin = ceil_lin;
+  p->knee_db = knee_db;
+  p->knee_start = ceil_lin / std::pow(10, knee_db / 20);           // dsp-worker.js:204-205
+  p->L = (int)std::floor(sr * lookahead_ms / 1000);                // dsp-worker.js:299-300
+  p->rc = std::exp(-1 / (release_ms * sr / 1000));
+  p->rcC = std::pow(p->rc, (double)C);
+  p->W = (int)std::floor(sr * 10 / 1000);                          // dsp-worker.js:308-309
+  p->pa = std::exp(-1 / (0.001 * sr));                             // dsp-worker.js:335-336
+  p->pr = std::exp(-1 / (0.050 * sr));
+  p->preserve = preserve;
+  if (p->L < 1 || p->L > 1024 || p->W < 1 || p->W > 1024) {
+    set_error("limiter lookahead (%d) / RMS window (%d) outside 1..1024 samples (sample rate %.1f)", p->L, p->W, sr);
+    return WAM_ERR_INVALID;
+  }
+  return WAM_OK;
+}
+
 // ---------------------------------------------------------------------------- staging helpers
 struct Staged {            // host planar channels <-> contiguous device [nch][n]
   DevBuf in, out;
@@ -106,6 +139,36 @@ int wam_glue_compressor(const float* const* ch, int nch, int64_t n, double sr, d
   FrontPlan fp;
   make_front_plan(sr, 0, 0, nullptr, 0, 1, threshold_db, ratio, attack_s, release_s, 0, 1.0, 0, 200, 0, &fp);
   return run_front_only(ch, nch, n, sr, fp, out);
+}
+
+int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double ceiling_db, double lookahead_ms, double release_ms,
+                  double drive, float* const* out) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  ClipPlan cp; rc = make_clip_plan(sr, ceiling_db, lookahead_ms, release_ms, drive, &cp); if (rc) return rc;
+  rc = ensure_device(); if (rc) return rc;
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  DevBuf plan, genv; rc = upload_plan(cp, plan, nullptr); if (rc) return rc;
+  rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
+  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), nullptr, nullptr);
+  if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
+}
+
+int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
+                double knee_db, int preserve_transients, float* const* out) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  LimiterPlan lp; rc = make_limiter_plan(sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients != 0, &lp); if (rc) return rc;
+  rc = ensure_device(); if (rc) return rc;
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  DevBuf plan, genv, tm; rc = upload_plan(lp, plan, nullptr); if (rc) return rc;
+  rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
+  rc = tm.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
+  rc = enqueue_limiter(st.in.as<float>(), st.out.as<float>(), tm.as<float>(), genv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(),
+                       preserve_transients != 0, nullptr, nullptr, 0, nullptr, nullptr);
+  if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
 }
 
 int wam_stereo(const float* const* ch, int64_t n, double sr, double width, int bass_mono, double bass_freq, float* const* out) {

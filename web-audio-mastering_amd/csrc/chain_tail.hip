@@ -1,0 +1,465 @@
+// chain_tail.hip - stages 8..10 of the export chain:
+//   stage 8 gain (normalizer.js:50-72) is folded into the loads of stage 9 (pre-gain G per track)
+//   stage 9 mastering soft clipper                  soft-clipper.js:165-294
+//       k_sc_env   : lookahead gain envelope (ramp minimum over the next L samples) + release smoothing
+//       k_sc_apply : gain, 2x Catmull-Rom oversampled saturation
+//   stage 10 lookahead true-peak limiter             dsp-worker.js:286-452
+//       k_lim_tm   : transient map (10 ms running RMS, 1 ms / 50 ms peak follower, crest factor)
+//       k_lim_gain : true-peak driven lookahead ramps (events are serial, each ramp wave-parallel) + release
+//       k_lim_apply: gain, oversampled soft knee, and the loudness / true-peak measurement of the result
+#include "chain.hpp"
+
+namespace wam {
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
+
+// exclusive block sum of one double per thread; total returned in `total`.  lds: 4 doubles.
+__device__ __forceinline__ double block_excl_sum(double v, double& total, double* lds) {
+  const int lane = lane_id(), wave = wave_id();
+  double inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  double off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) { if (w < wave) off += lds[w]; tot += lds[w]; }
+  total = tot;
+  return off + inc - v;
+}
+
+// ============================================================================ soft clipper
+// Envelope.  One workgroup per track.  g_out: [ntracks][n] float.
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ in, int64_t n, const ClipPlan* __restrict__ cp,
+                                                     const double* __restrict__ gains, float* __restrict__ g_out) {
+  constexpr int kMaxL = 256;
+  __shared__ double rr[kMaxL + kTile];           // required gain per sample of [tile_base - L, tile_end); 2.0 = no event
+  __shared__ double lds_scan[kSlotDoubles];
+  const ClipPlan& P = *cp;
+  const int L = P.L;
+  const int64_t trk = blockIdx.x;
+  const double G = gains ? gains[trk] : 1.0;
+  float* go = g_out + trk * n;
+  LdsSlots slots(lds_scan);
+  double Scur = 1.0;
+  for (int i = threadIdx.x; i < L; i += kThreads) rr[i] = 2.0;
+  const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    double r[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) r[k] = 2.0;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v[C];
+      load_chunk(in + (trk * NCH + c) * n, n, base, v);
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const double a = fabs((double)f32r((double)v[k] * G));
+        if (a > P.thr_lin && base + k < n) {
+          // soft-clipper.js:200-207
+          const double excess = a - P.thr_lin;
+          const double normalized = excess / P.range_div;
+          const double sat = tanh(normalized * P.drive);
+          const double target = P.thr_lin + sat * P.range;
+          r[k] = fmin(r[k], target / a);
+          any = true;
+        }
+      }
+    }
+    __syncthreads();      // previous tile's readers of rr are done
+#pragma unroll
+    for (int k = 0; k < C; k++) rr[L + threadIdx.x * C + k] = r[k];
+    const int any_blk = __syncthreads_or(any);
+    // the window also holds the previous tile's last L samples: remember whether those had events
+    __shared__ int prev_any;
+    if (t == 0 && threadIdx.x == 0) prev_any = 0;
+    __syncthreads();
+    const int active = any_blk | prev_any;
+    // finalised samples of this tile: k in [tile_base - L, tile_end - L)
+    float g[C];
+    const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
+#pragma unroll
+    for (int k = 0; k < C; k++) g[k] = 1.0f;
+    if (active) {
+#pragma unroll 1
+      for (int k = 0; k < C; k++) {
+        const int64_t kk = kb + k;
+        if (kk < 0 || kk >= n) continue;
+        float gm = 1.0f;
+        const int wl = threadIdx.x * C + k;            // window index of kk
+        for (int d = 0; d <= L; d++) {
+          const double req = rr[wl + d];
+          if (req < 1.5) {
+            const int64_t i = kk + d;
+            const int64_t st = i - L > 0 ? i - L : 0;
+            const double tt = (double)(kk - st) / (double)(i - st > 1 ? i - st : 1);      // soft-clipper.js:213-214
+            gm = fminf(gm, f32r(1.0 + (req - 1.0) * tt));
+          }
+        }
+        g[k] = gm;
+      }
+    }
+    // release smoothing (soft-clipper.js:222-231) over the finalised samples, in time order across tiles
+    float gs[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) gs[k] = (kb + k >= 0 && kb + k < n) ? g[k] : 1.0f;
+    // samples before 0 (first tile) are skipped: treat them as "no step" by making them pure releases from 1.0 (cur stays 1)
+    double cur = release_solve(gs, P.rc, P.rcC, Scur, slots.next());
+#pragma unroll
+    for (int k = 0; k < C; k++) { cur = release_step(cur, (double)gs[k], P.rc); g[k] = f32r(cur); }
+    if (kb + C > 0) {
+      if (kb >= 0) store_chunk(go, n, kb, g);
+      else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
+    }
+    __syncthreads();
+    // slide the window
+    double keep = 2.0;
+    if (threadIdx.x < L) keep = rr[kTile + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < L) rr[threadIdx.x] = keep;
+    if (threadIdx.x == 0) prev_any = any_blk;
+  }
+}
+
+// Apply.  One workgroup per (track, channel), grid-stride over tiles is not needed: elementwise with halo.
+__global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
+                                                       const ClipPlan* __restrict__ cp, const double* __restrict__ gains,
+                                                       const float* __restrict__ genv) {
+  const ClipPlan& P = *cp;
+  const int64_t chan = blockIdx.y;
+  const int64_t trk = chan / nch;
+  const double G = gains ? gains[trk] : 1.0;
+  const float* x = in + chan * n;
+  const float* g = genv + trk * n;
+  float* y = out + chan * n;
+  const double ceil_lin = P.ceil_lin;
+  for (int64_t base = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * C; base < n; base += (int64_t)gridDim.x * kThreads * C) {
+    float xv[C + 3], gv[C + 3];        // samples base-1 .. base+C+1
+    {
+      float v[C], w[C];
+      load_chunk(x, n, base, v);
+      load_chunk(g, n, base, w);
+#pragma unroll
+      for (int k = 0; k < C; k++) { xv[k + 1] = v[k]; gv[k + 1] = w[k]; }
+      xv[0] = base - 1 >= 0 ? x[base - 1] : 0.0f; gv[0] = base - 1 >= 0 ? g[base - 1] : 1.0f;
+      xv[C + 1] = base + C < n ? x[base + C] : 0.0f; gv[C + 1] = base + C < n ? g[base + C] : 1.0f;
+      xv[C + 2] = base + C + 1 < n ? x[base + C + 1] : 0.0f; gv[C + 2] = base + C + 1 < n ? g[base + C + 1] : 1.0f;
+    }
+    double s[C + 3];
+#pragma unroll
+    for (int k = 0; k < C + 3; k++) {
+      const int64_t i = base - 1 + k;
+      double xi = (double)f32r((double)xv[k] * G);
+      double gi = gv[k];
+      if (i < 0 || i >= n) { xi = 0; gi = 1; }
+      if (!(xi == xi)) xi = 0;                      // input[k] || 0 for NaN (neighbours only; see below)
+      if (gi == 0 || !(gi == gi)) gi = 1;           // gainEnvelope[k] || 1
+      s[k] = xi * gi;
+    }
+    float o[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      // centre sample uses input[i] * gainEnvelope[i] without the || fallbacks (soft-clipper.js:242,249)
+      const double p2 = (double)f32r((double)xv[k + 1] * G), g2 = gv[k + 1];
+      double sA = p2 * g2;
+      double sB = catmull_half(s[k], p2 * g2, s[k + 2], s[k + 3]);
+      double v2[2] = { sA, sB };
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double a = fabs(v2[q]);
+        if (a > ceil_lin) {
+          const double ex = (a - ceil_lin) / ceil_lin;
+          const double red = 1 - tanh(ex * 2) * 0.1;
+          const double m = fmin(a * red, ceil_lin);
+          v2[q] = v2[q] > 0 ? m : -m;
+        }
+      }
+      o[k] = f32r((v2[0] + v2[1]) * 0.5);
+    }
+    store_chunk(y, n, base, o);
+  }
+}
+
+// ============================================================================ limiter
+// Transient map (dsp-worker.js:306-362).  One workgroup per track.  tm: [ntracks][n] float.
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
+                                                     float* __restrict__ tm_out) {
+  constexpr int kMaxW = 1024;
+  __shared__ double pre[kTile + kTile / 16 + 8];       // padded inclusive prefix of the tile's mean squares
+  __shared__ double tail[kMaxW + kMaxW / 16 + 8];      // previous tile's last W prefixes, relative to this tile's origin
+  __shared__ double lds_scan[kSlotDoubles];
+  __shared__ double lds_sum[4];
+  const LimiterPlan& P = *lp;
+  const int W = P.W;
+  const int64_t trk = blockIdx.x;
+  float* tmo = tm_out + trk * n;
+  LdsSlots slots(lds_scan);
+  double Spk = 0;
+  for (int i = threadIdx.x; i < kMaxW + kMaxW / 16 + 8; i += kThreads) tail[i] = 0;
+  __syncthreads();
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    double q[C], pk[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) { q[k] = 0; pk[k] = 0; }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v[C];
+      load_chunk(in + (trk * NCH + c) * n, n, base, v);
+#pragma unroll
+      for (int k = 0; k < C; k++) { const double d = v[k]; q[k] += d * d; pk[k] = fmax(pk[k], fabs(d)); }
+    }
+    double run = 0;
+#pragma unroll
+    for (int k = 0; k < C; k++) { q[k] /= NCH; run += q[k]; q[k] = run; }       // local inclusive prefix
+    double total;
+    const double off = block_excl_sum(run, total, lds_sum);
+#pragma unroll
+    for (int k = 0; k < C; k++) pre[padi(threadIdx.x * C + k)] = off + q[k];
+    // peak follower (dsp-worker.js:334-351)
+    double e = follower_solve(pk, P.pa, P.pr, Spk, slots.next());      // contains barriers: pre[] is visible after it
+    float tmv[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      e = follower_step(e, pk[k], P.pa, P.pr);
+      const int j = threadIdx.x * C + k;
+      const int64_t i = base + k;
+      const double hi = off + q[k];
+      const double lo = (j - W >= 0) ? pre[padi(j - W)] : tail[padi(j)];
+      const int64_t ws = i + 1 < W ? i + 1 : W;
+      const float rms = f32r(sqrt((hi - lo) / (double)ws));
+      const float pke = f32r(e);
+      float tmk = 0.0f;
+      if (rms > 0.0001f) {
+        const double ratio = (double)pke / (double)rms;
+        const double crest = 20.0 * 0.30102999566398120 * (double)log2f((float)ratio);     // 20 log10(x) = 20 log10(2) log2(x)
+        tmk = f32r(fmin(1.0, fmax(0.0, (crest - 6) / (10 - 6))));
+      }
+      tmv[k] = tmk;
+    }
+    store_chunk(tmo, n, base, tmv);
+    __syncthreads();
+    // next tile's tail = this tile's last W prefixes minus this tile's total
+    double keep[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; keep[r] = (m < W) ? pre[padi(kTile - W + m)] - total : 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; if (m < W) tail[padi(m)] = keep[r]; }
+    __syncthreads();
+  }
+}
+
+// Lookahead gain (dsp-worker.js:367-425).  One workgroup per track.  g_out: [ntracks][n] float.
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
+                                                       const float* __restrict__ tm, float* __restrict__ g_out) {
+  constexpr int kMaxL = 1024;
+  __shared__ float gwin_s[kMaxL + kTile];       // gain envelope of [tile_base - L, tile_end)
+  __shared__ double lds_scan[kSlotDoubles];
+  __shared__ float ctx[NCH][kCtxFloats];
+  volatile float* gwin = gwin_s;
+  const LimiterPlan& P = *lp;
+  const int L = P.L;
+  const int64_t trk = blockIdx.x;
+  const float* tmi = tm ? tm + trk * n : nullptr;
+  float* go = g_out + trk * n;
+  LdsSlots slots(lds_scan);
+  double Scur = 1.0;
+  for (int i = threadIdx.x; i < L + kTile; i += kThreads) gwin[i] = 1.0f;
+  __syncthreads();
+  const int lane = lane_id(), wave = wave_id();
+  const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    const int par = (int)(t & 1);
+    // per-sample true peak over the channels and the required gain (dsp-worker.js:373-403)
+    double tp[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) tp[k] = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float v[C], xp[3];
+      load_chunk(in + (trk * NCH + c) * n, n, base, v);
+      const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
+      prev_ctx<3>(last, xp, ctx[c], par, t == 0);
+      double y0 = xp[0], y1 = xp[1], y2 = xp[2];
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const double y3 = v[k];
+        if (base + k >= 3 && base + k < n) tp[k] = fmax(tp[k], true_peak4(y0, y1, y2, y3));
+        y0 = y1; y1 = y2; y2 = y3;
+      }
+    }
+    float tmv[C];
+    if (tmi) load_chunk(tmi, n, base, tmv);
+    double req[C];
+    unsigned evbits = 0;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      double ec = P.ceil_lin;
+      if (tmi && tmv[k] > 0.5f) ec = P.ceil_lin * (double)exp2f((float)((double)tmv[k] * 0.5 / 20.0 * 3.3219280948873623));   // 10^(tm 0.5/20)
+      req[k] = 1.0;
+      if (tp[k] > ec && base + k < n) { req[k] = ec / tp[k]; evbits |= 1u << k; }
+    }
+    // events in time order: waves in turn, lanes in turn, samples in turn; each ramp is applied by the whole wave
+    for (int w = 0; w < kWaves; w++) {
+      if (w == wave) {
+        unsigned long long m = __ballot(evbits != 0);
+        while (m) {
+          const int src = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const unsigned bits = __shfl(evbits, src);
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const double rq = __shfl(req[k], src);
+            if (bits & (1u << k)) {           // wave-uniform
+              const int64_t i = tile_base + (int64_t)(w * 64 + src) * C + k;
+              const int64_t tg = i - L > 0 ? i - L : 0;
+              const int wl_t = (int)(tg - (tile_base - L));
+              const int cnt = (int)(i - tg) + 1;
+              const double Gt = (double)gwin[wl_t];
+              if (rq < Gt) {
+                for (int j = lane; j < cnt; j += 64) {
+                  const double prog = (double)j / (double)L;                 // (j - targetIndex) / lookaheadSamples
+                  const double sm = Gt + (rq - Gt) * prog;
+                  const float old = gwin[wl_t + j];
+                  gwin[wl_t + j] = f32r(fmin((double)old, sm));
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // finalised samples [tile_base - L, tile_end - L): release smoothing (dsp-worker.js:416-425)
+    const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
+    float gs[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) { const float gv = gwin[threadIdx.x * C + k]; gs[k] = (kb + k >= 0 && kb + k < n) ? gv : 1.0f; }
+    double cur = release_solve(gs, P.rc, P.rcC, Scur, slots.next());
+    float g[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) { cur = release_step(cur, (double)gs[k], P.rc); g[k] = f32r(cur); }
+    if (kb + C > 0) {
+      if (kb >= 0) store_chunk(go, n, kb, g);
+      else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
+    }
+    __syncthreads();
+    // slide the window by one tile
+    float keep[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; keep[r] = (m < L) ? gwin[kTile + m] : 1.0f; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; if (m < L) gwin[m] = keep[r]; }
+    for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = 1.0f;
+    __syncthreads();
+  }
+}
+
+// dsp-worker.js:197-229 applySoftKneeCurve
+__device__ __forceinline__ double soft_knee_curve(double s, double ceiling, double knee_start) {
+  const double a = fabs(s);
+  if (a <= ceiling * 0.9) return s;
+  if (a <= knee_start) return s;
+  double o;
+  if (a <= ceiling) {
+    const double t = (a - knee_start) / (ceiling - knee_start);
+    const double blend = t * t * (3 - 2 * t);
+    o = a + (ceiling - a) * blend * 0.5;
+  } else {
+    const double nrm = (a - ceiling) / ceiling;
+    const double comp = 1 - tanh(nrm * 2) * 0.1;
+    o = fmin(ceiling, a * comp);
+  }
+  return s > 0 ? o : -o;
+}
+
+// Apply + soft knee (dsp-worker.js:430-449, :234-281) + final metering.  One workgroup per (track, channel).
+__global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
+                                                        const LimiterPlan* __restrict__ lp, const float* __restrict__ genv,
+                                                        const MeterPlan* __restrict__ mp, double* __restrict__ hopsums, int64_t hop_stride,
+                                                        double* __restrict__ peaks) {
+  __shared__ double lds_meter[kMeterLds];
+  __shared__ float ctx[2][kCtxFloats];
+  const LimiterPlan& P = *lp;
+  const int64_t chan = blockIdx.x;
+  const int64_t trk = chan / nch;
+  const float* x = in + chan * n;
+  const float* g = genv + trk * n;
+  float* y = out + chan * n;
+  MeterState ms;
+  if (mp) meter_init(ms, *mp, 0);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    const int par = (int)(t & 1);
+    float v[C], gv[C], s[C];
+    load_chunk(x, n, base, v);
+    load_chunk(g, n, base, gv);
+#pragma unroll
+    for (int k = 0; k < C; k++) s[k] = f32r((double)v[k] * (double)gv[k]);
+    const float last[3] = { s[C - 3], s[C - 2], s[C - 1] };
+    float sp[3];
+    prev_ctx<3>(last, sp, ctx[0], par, t == 0);
+    float o[C];
+    double y0 = sp[0], y1 = sp[1], y2 = sp[2];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const double y3 = s[k];
+      double r = y3;
+      if (base + k >= 3) {
+        const double m = true_peak4(y0, y1, y2, y3);
+        if (m > P.ceil_lin) r = y3 * (P.ceil_lin / m);
+      }
+      o[k] = f32r(soft_knee_curve(r, P.ceil_lin, P.knee_start));
+      y0 = y1; y1 = y2; y2 = y3;
+    }
+    store_chunk(y, n, base, o);
+    if (mp) {
+      const float lo[3] = { o[C - 3], o[C - 2], o[C - 1] };
+      float op[3];
+      prev_ctx<3>(lo, op, ctx[1], par, t == 0);
+      meter_chunk(o, op, base, tile_base, n, *mp, ms, lds_meter, hopsums + chan * hop_stride);
+    }
+  }
+  if (mp) meter_finish(ms, lds_meter, peaks + chan);
+}
+
+// ---------------------------------------------------------------------------- launchers
+int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev,
+                      const double* gains_dev, hipStream_t s) {
+  if (n <= 0) return WAM_OK;
+  if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv);
+  else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv);
+  int64_t bx = (n + (int64_t)kThreads * C - 1) / ((int64_t)kThreads * C); if (bx > 64) bx = 64;
+  WAM_LAUNCH("k_sc_apply", k_sc_apply, dim3((unsigned)bx, (unsigned)(ntracks * nch)), dim3(kThreads), s, in, out, nch, n, plan_dev, gains_dev, (const float*)genv);
+  return WAM_OK;
+}
+
+int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev,
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s) {
+  if (n <= 0) return WAM_OK;
+  if (preserve) {
+    if (nch == 2) WAM_LAUNCH("k_lim_tm", k_lim_tm<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tm);
+    else WAM_LAUNCH("k_lim_tm", k_lim_tm<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tm);
+  }
+  const float* tmi = preserve ? tm : nullptr;
+  if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv);
+  else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv);
+  WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, (const float*)genv, meter_dev, hopsums, hop_stride, peaks);
+  return WAM_OK;
+}
+
+}  // namespace wam
