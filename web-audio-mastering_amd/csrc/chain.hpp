@@ -29,7 +29,7 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
   Biquad w_lp1, w_hp1, w_lp2, w_hp2;
   Biquad p_lp1, p_hp1, p_lp2, p_hp2;
   double w_drive[3], w_bias[3], w_mix[3], w_bo[3], w_mk[3];
-  int64_t w_ws, w_nw;          // bypass-envelope window (samples) and count
+  int64_t w_ws, w_nw, w_lw;    // bypass-envelope window (samples), count, lookahead windows
   double pf_A[3], pf_R[3], ps_A[3], ps_R[3], p_tg[3], p_sg[3];
   OnePole p_smooth;
 };
@@ -42,6 +42,13 @@ int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int
                       const double* gains_dev, hipStream_t s);
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev,
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s);
+
+int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, hipStream_t s);
+int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const HeavyPlan& hp_host, unsigned* winpeak, float* sm, float* env,
+                     double pre_gain, hipStream_t s);
+int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
+                       const float* env, double pre_gain, hipStream_t s);
+void make_heavy_plan(double sr, int64_t n, HeavyPlan* p);
 
 void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains, int cut_mud,
                      int do_glue, double glue_thr_db, double glue_ratio, double glue_attack, double glue_release,

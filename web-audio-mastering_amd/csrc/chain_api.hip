@@ -36,6 +36,33 @@ void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains /
   p->side_gain = std::pow(10, 0 / 20.0) * width;                   // dsp-worker.js:1187
 }
 
+void make_heavy_plan(double sr, int64_t n, HeavyPlan* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->exc_hp = exciter_hp(sr, 6000);                                        // constants.js:37
+  const double Qw = 0.7071067811865476;                                    // multiband-saturation.js:67
+  p->w_lp1 = rbj_pass(sr, 200, Qw, false); p->w_hp1 = rbj_pass(sr, 200, Qw, true);
+  p->w_lp2 = rbj_pass(sr, 4000, Qw, false); p->w_hp2 = rbj_pass(sr, 4000, Qw, true);
+  p->p_lp1 = rbj_pass(sr, 200, 0.707, false); p->p_hp1 = rbj_pass(sr, 200, 0.707, true);   // multiband-transient.js:101-110
+  p->p_lp2 = rbj_pass(sr, 4000, 0.707, false); p->p_hp2 = rbj_pass(sr, 4000, 0.707, true);
+  static const double drive[3] = {0.2, 0.4, 0.3}, bias[3] = {0.0, 0.1, 0.05}, mix[3] = {0.3, 0.5, 0.4};   // multiband-saturation.js:27-36
+  for (int b = 0; b < 3; b++) {
+    p->w_drive[b] = drive[b]; p->w_bias[b] = bias[b]; p->w_mix[b] = mix[b];
+    p->w_bo[b] = std::tanh(drive[b] * bias[b]);                            // :285
+    p->w_mk[b] = 1 / std::tanh(std::fmax(drive[b], 0.1));                  // :290
+  }
+  p->w_ws = (int64_t)std::floor(sr * 100 / 1000);                          // :206
+  p->w_nw = p->w_ws > 0 ? (n + p->w_ws - 1) / p->w_ws : 0;                 // :207
+  p->w_lw = p->w_ws > 0 ? (int64_t)std::ceil(sr * 5 / 1000 / (double)p->w_ws) : 0;   // :257
+  static const double fa[3] = {0.005, 0.001, 0.003}, fr[3] = {0.050, 0.040, 0.030}, sa[3] = {0.025, 0.020, 0.015},
+                      srl[3] = {0.250, 0.200, 0.150}, tg[3] = {2, 6, 2}, sg[3] = {-1, 0, 0};           // multiband-transient.js:25-53
+  for (int b = 0; b < 3; b++) {
+    p->pf_A[b] = std::exp(-1 / (fa[b] * sr)); p->pf_R[b] = std::exp(-1 / (fr[b] * sr));
+    p->ps_A[b] = std::exp(-1 / (sa[b] * sr)); p->ps_R[b] = std::exp(-1 / (srl[b] * sr));
+    p->p_tg[b] = std::pow(10, tg[b] / 20); p->p_sg[b] = std::pow(10, sg[b] / 20);
+  }
+  p->p_smooth = make_onepole(std::exp(-1 / (0.020 * sr)));
+}
+
 int make_clip_plan(double sr, double ceiling_db, double lookahead_ms, double release_ms, double drive, ClipPlan* p) {
   std::memset(p, 0, sizeof(*p));
   p->ceil_lin = std::pow(10, ceiling_db / 20);                     // soft-clipper.js:177-180
@@ -170,6 +197,37 @@ int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ce
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
+
+static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int which, float* const* out) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  HeavyPlan hp; make_heavy_plan(sr, n, &hp);
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  DevBuf plan; rc = upload_plan(hp, plan, nullptr); if (rc) return rc;
+  if (which == 0) {
+    rc = enqueue_exciter(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1.0, nullptr);
+  } else if (which == 1) {
+    DevBuf wp, sm, env;
+    const size_t nw = (size_t)(hp.w_nw > 0 ? hp.w_nw : 1);
+    rc = wp.alloc(sizeof(unsigned) * nw); if (rc) return rc;
+    rc = sm.alloc(sizeof(float) * nw); if (rc) return rc;
+    rc = env.alloc(sizeof(float) * nw); if (rc) return rc;
+    rc = enqueue_warm_env(st.in.as<float>(), 1, nch, n, hp, wp.as<unsigned>(), sm.as<float>(), env.as<float>(), 1.0, nullptr);
+    if (rc) return rc;
+    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1, 0, env.as<float>(), 1.0, nullptr);
+    if (rc) return rc;
+    return st.down(st.out.as<float>(), out, nullptr);
+  } else {
+    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 0, 1, nullptr, 1.0, nullptr);
+  }
+  if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
+}
+
+int wam_exciter(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 0, out); }
+int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 1, out); }
+int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 2, out); }
 
 int wam_stereo(const float* const* ch, int64_t n, double sr, double width, int bass_mono, double bass_freq, float* const* out) {
   FrontPlan fp;
