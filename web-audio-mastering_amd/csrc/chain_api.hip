@@ -141,6 +141,208 @@ static int run_front_only(const float* const* ch, int nch, int64_t n, double sr,
   return st.down(st.out.as<float>(), out, nullptr);
 }
 
+
+// ---------------------------------------------------------------------------- RENDER_FULL_CHAIN driver
+struct Progress {
+  wam_progress_cb cb; void* user; hipStream_t stream;
+  int operator()(double p, const char* status) const {
+    if (!cb) return WAM_OK;
+    WAM_HIP(hipStreamSynchronize(stream));            // report a stage once the previous ones are really done
+    if (cb(p, status, user)) { set_error("Cancelled"); return WAM_ERR_CANCELLED; }
+    return WAM_OK;
+  }
+};
+
+static double js_number_or_zero(double v) { return (v == v) ? v : 0.0; }   // Number(x) || 0
+
+// One group of tracks, everything device-resident.  dsp-worker.js:1468-1667.
+static int render_group(const float* in, float* out, int T, int nch, int64_t n, double sr, const wam_settings& st, int mode,
+                        wam_result* results, hipStream_t stream, const Progress& prog) {
+  int rc;
+  const bool exp_mode = mode == WAM_MODE_EXPORT;
+  const double ig_db = js_number_or_zero(st.input_gain);
+  double pending_gain = ig_db != 0 ? std::pow(10, ig_db / 20) : 1.0;       // dsp-worker.js:1493-1496
+  const bool do_deharsh = st.deharsh != 0, do_exc = st.add_air != 0, do_warm = st.tape_warmth != 0, do_punch = st.add_punch != 0;
+  const double target = st.target_lufs;
+  const bool do_norm = exp_mode && st.normalize_loudness && target != 0 && target == target;      // :1602
+  const bool do_limit = exp_mode && st.true_peak_limit;
+  const double ceiling_db = (st.true_peak_ceiling != 0 && st.true_peak_ceiling == st.true_peak_ceiling) ? st.true_peak_ceiling : -1;   // :1612
+  double eq[5] = { js_number_or_zero(st.eq_low), js_number_or_zero(st.eq_low_mid), js_number_or_zero(st.eq_mid),
+                   js_number_or_zero(st.eq_high_mid), js_number_or_zero(st.eq_high) };
+  bool do_stereo = false; double width = 1.0;
+  if (nch == 2) {                                                          // :1582-1588
+    const double w = std::isfinite(st.stereo_width) ? st.stereo_width / 100 : 1.0;
+    width = std::fmax(0.0, std::fmin(2.0, w));
+    do_stereo = st.center_bass || std::fabs(width - 1.0) > 1e-6;
+  }
+  if (do_deharsh) {
+#ifndef WAM_HAVE_DEHARSH
+    set_error("de-harsh stage is not available in this build"); return WAM_ERR_INVALID;
+#endif
+  }
+
+  // ---- plans
+  MeterPlan mp; rc = make_meter_plan(nch, n, sr, -14.0, &mp); if (rc) return rc;
+  HeavyPlan hp; make_heavy_plan(sr, n, &hp);
+  FrontPlan fp;
+  make_front_plan(sr, st.clean_low_end != 0, 1, eq, st.cut_mud != 0, st.glue_compression != 0, -18, 3, 0.02, 0.25,
+                  do_stereo, width, st.center_bass != 0, 200, (do_norm || !do_limit) ? 1 : 0, &fp);
+  ClipPlan cp; LimiterPlan lp;
+  if (do_limit) {
+    rc = make_clip_plan(sr, ceiling_db, 0.5, 10, 1.5, &cp); if (rc) return rc;
+    rc = make_limiter_plan(sr, std::pow(10, ceiling_db / 20), 3, 100, 3, 1, &lp); if (rc) return rc;
+  }
+
+  // ---- scratch
+  const size_t chan_elems = (size_t)(n > 0 ? n : 1);
+  const size_t nw = (size_t)(hp.w_nw > 0 ? hp.w_nw : 1);
+  DevBuf B1, tmb, genv, wpk, wsm, wenv, m1b, m2b, plans, gains_b;
+  rc = B1.alloc(sizeof(float) * chan_elems * nch * T); if (rc) return rc;
+  if (do_limit) { rc = tmb.alloc(sizeof(float) * chan_elems * T); if (rc) return rc; rc = genv.alloc(sizeof(float) * chan_elems * T); if (rc) return rc; }
+  if (do_warm) {
+    rc = wpk.alloc(sizeof(unsigned) * nw * T); if (rc) return rc;
+    rc = wsm.alloc(sizeof(float) * nw * T); if (rc) return rc;
+    rc = wenv.alloc(sizeof(float) * nw * T); if (rc) return rc;
+  }
+  rc = m1b.alloc(meter_scratch_bytes(mp, T, false)); if (rc) return rc;
+  rc = m2b.alloc(meter_scratch_bytes(mp, T, false)); if (rc) return rc;
+  MeterScratch M1, M2;
+  carve_meter_scratch(mp, T, false, m1b.p, &M1);
+  carve_meter_scratch(mp, T, false, m2b.p, &M2);
+  WAM_HIP(hipMemcpyAsync(M1.plan, &mp, sizeof(mp), hipMemcpyHostToDevice, stream));
+  WAM_HIP(hipMemcpyAsync(M2.plan, &mp, sizeof(mp), hipMemcpyHostToDevice, stream));
+  const size_t off_h = 0, off_f = align_up(sizeof(HeavyPlan), 256), off_c = off_f + align_up(sizeof(FrontPlan), 256),
+               off_l = off_c + align_up(sizeof(ClipPlan), 256), plan_bytes = off_l + align_up(sizeof(LimiterPlan), 256);
+  rc = plans.alloc(plan_bytes); if (rc) return rc;
+  char* pb = (char*)plans.p;
+  WAM_HIP(hipMemcpyAsync(pb + off_h, &hp, sizeof(hp), hipMemcpyHostToDevice, stream));
+  WAM_HIP(hipMemcpyAsync(pb + off_f, &fp, sizeof(fp), hipMemcpyHostToDevice, stream));
+  if (do_limit) {
+    WAM_HIP(hipMemcpyAsync(pb + off_c, &cp, sizeof(cp), hipMemcpyHostToDevice, stream));
+    WAM_HIP(hipMemcpyAsync(pb + off_l, &lp, sizeof(lp), hipMemcpyHostToDevice, stream));
+  }
+  const HeavyPlan* hp_d = (const HeavyPlan*)(pb + off_h);
+  const FrontPlan* fp_d = (const FrontPlan*)(pb + off_f);
+  const ClipPlan* cp_d = (const ClipPlan*)(pb + off_c);
+  const LimiterPlan* lp_d = (const LimiterPlan*)(pb + off_l);
+  rc = gains_b.alloc(sizeof(double) * 2 * (size_t)T); if (rc) return rc;
+  double* gains_d = gains_b.as<double>();
+  double* lufs_in_d = gains_d + T;
+
+  // ---- buffer ping-pong: the last full-buffer write must land in `out`
+  int nwrites = (do_deharsh ? 1 : 0) + (do_exc ? 1 : 0) + ((do_warm || do_punch) ? 1 : 0);
+  if (exp_mode) nwrites += 1 + (do_limit ? 2 : (do_norm ? 1 : 0));
+  const float* src = in;
+  float* bufs[2] = { B1.as<float>(), out };
+  int wi = (nwrites & 1) ? 1 : 0;                     // index of the first destination
+  auto next_dst = [&]() { float* d = bufs[wi]; wi ^= 1; return d; };
+
+  rc = prog(0.05, "Creating audio buffer..."); if (rc) return rc;
+  if (ig_db != 0) { rc = prog(0.10, "Applying input gain..."); if (rc) return rc; }
+  if (do_deharsh) {
+    rc = prog(0.15, "Applying hybrid dynamic processor..."); if (rc) return rc;
+#ifdef WAM_HAVE_DEHARSH
+    float* dst = next_dst();
+    rc = enqueue_deharsh(src, dst, T, nch, n, sr, pending_gain, stream); if (rc) return rc;
+    src = dst; pending_gain = 1.0;
+#endif
+  }
+  if (do_exc) {
+    rc = prog(0.3, "Applying exciter..."); if (rc) return rc;
+    float* dst = next_dst();
+    rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, stream); if (rc) return rc;
+    src = dst; pending_gain = 1.0;
+  }
+  if (do_warm) { rc = prog(0.45, "Applying multiband saturation..."); if (rc) return rc; }
+  if (do_punch) { rc = prog(0.55, "Applying multiband transient..."); if (rc) return rc; }
+  if (do_warm || do_punch) {
+    if (do_warm) { rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream); if (rc) return rc; }
+    float* dst = next_dst();
+    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, do_warm, do_punch, do_warm ? wenv.as<float>() : nullptr, pending_gain, stream); if (rc) return rc;
+    src = dst; pending_gain = 1.0;
+  }
+
+  const MeterScratch* final_meter = nullptr;
+  bool have_gain = false;
+  if (!exp_mode) {
+    // preview: heavy FX only, then measureLUFS (dsp-worker.js:1530-1551)
+    if (nwrites == 0) {
+      std::vector<double> g(T, pending_gain);
+      WAM_HIP(hipMemcpyAsync(gains_d, g.data(), sizeof(double) * T, hipMemcpyHostToDevice, stream));
+      rc = enqueue_gain_meter(src, out, T, nch, n, pending_gain != 1.0 ? gains_d : nullptr, mp, M2, stream); if (rc) return rc;
+      WAM_HIP(hipStreamSynchronize(stream));          // g is a host temporary
+    } else {
+      rc = enqueue_gain_meter(src, nullptr, T, nch, n, nullptr, mp, M2, stream); if (rc) return rc;
+    }
+    final_meter = &M2;
+  } else {
+    rc = prog(0.60, "Applying final filters..."); if (rc) return rc;
+    rc = prog(0.65, "Applying EQ..."); if (rc) return rc;
+    if (st.glue_compression) { rc = prog(0.70, "Applying glue compressor..."); if (rc) return rc; }
+    if (do_stereo) { rc = prog(0.72, "Applying stereo processing..."); if (rc) return rc; }
+    {
+      float* dst = next_dst();
+      if (fp.do_meter) WAM_HIP(hipMemsetAsync(M1.hopsums, 0, M1.hopsums_bytes, stream));
+      rc = enqueue_front(src, dst, T, nch, n, fp_d, M1.plan, M1.hopsums, M1.hop_stride, M1.peaks, pending_gain, stream); if (rc) return rc;
+      src = dst; pending_gain = 1.0;
+      if (fp.do_meter) { rc = enqueue_gate(mp, T, M1, stream); if (rc) return rc; final_meter = &M1; }
+    }
+    if (do_norm) {
+      rc = prog(0.75, "Analyzing loudness..."); if (rc) return rc;
+      rc = enqueue_norm_gain(M1, T, target, gains_d, lufs_in_d, stream); if (rc) return rc;
+      have_gain = true;
+    }
+    if (do_limit) {
+      rc = prog(0.85, "Applying soft clipper..."); if (rc) return rc;
+      float* dst = next_dst();
+      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, have_gain ? gains_d : nullptr, stream); if (rc) return rc;
+      src = dst;
+      rc = prog(0.95, "Applying final limiter..."); if (rc) return rc;
+      dst = next_dst();
+      WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, stream));
+      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, stream); if (rc) return rc;
+      src = dst;
+      rc = enqueue_gate(mp, T, M2, stream); if (rc) return rc;
+      final_meter = &M2;
+    } else if (do_norm) {
+      float* dst = next_dst();
+      rc = enqueue_gain_meter(src, dst, T, nch, n, gains_d, mp, M2, stream); if (rc) return rc;
+      src = dst;
+      final_meter = &M2;
+    }
+  }
+  // ---- results
+  std::vector<GateOut> g(T);
+  std::vector<double> gl(2 * (size_t)T, 0.0);
+  WAM_HIP(hipMemcpyAsync(g.data(), final_meter->gate, sizeof(GateOut) * T, hipMemcpyDeviceToHost, stream));
+  if (have_gain) WAM_HIP(hipMemcpyAsync(gl.data(), gains_d, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, stream));
+  WAM_HIP(hipStreamSynchronize(stream));
+  for (int t = 0; t < T && results; t++) {
+    wam_result& r = results[t];
+    r.lufs = r.measured_lufs = finish_lufs(mp, g[t]);
+    r.true_peak_db = finish_peak_db(g[t]);
+    r.lufs_in = have_gain ? gl[(size_t)T + t] : NAN;
+    r.gain_db = (have_gain && std::isfinite(r.lufs_in)) ? target - r.lufs_in : 0.0;
+  }
+  if (prog.cb && prog.cb(1.0, "Complete", prog.user)) { set_error("Cancelled"); return WAM_ERR_CANCELLED; }
+  return WAM_OK;
+}
+
+static int render_batch_dev(const float* in, float* out, int T, int nch, int64_t n, double sr, const wam_settings* st, int mode,
+                            wam_result* results, hipStream_t stream, wam_progress_cb cb, void* user) {
+  if (!in || !out || !st || T < 1 || nch < 1 || nch > 2 || n < 0 || !(sr > 0)) { set_error("invalid render arguments"); return WAM_ERR_INVALID; }
+  int rc = ensure_device(); if (rc) return rc;
+  const Progress prog{cb, user, stream};
+  const int group = 256;                              // bounds the scratch: ~2.5 x the group's audio
+  for (int t0 = 0; t0 < T; t0 += group) {
+    const int g = T - t0 < group ? T - t0 : group;
+    const size_t off = (size_t)t0 * nch * (size_t)n;
+    rc = render_group(in + off, out + off, g, nch, n, sr, *st, mode, results ? results + t0 : nullptr, stream, prog);
+    if (rc) return rc;
+  }
+  return WAM_OK;
+}
+
 }  // namespace wam
 
 using namespace wam;
@@ -228,6 +430,44 @@ static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int 
 int wam_exciter(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 0, out); }
 int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 1, out); }
 int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 2, out); }
+
+int wam_render_chain(const float* const* ch, int nch, int64_t n, double sr, const wam_settings* settings, int mode, float* const* out,
+                     wam_result* result, wam_progress_cb progress, void* user) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!settings || !(sr > 0)) { set_error("invalid render arguments"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  rc = render_batch_dev(st.in.as<float>(), st.out.as<float>(), 1, nch, n, sr, settings, mode, result, nullptr, progress, user);
+  if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
+}
+
+int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
+                         float* out_dev, wam_result* results, void* stream) {
+  return render_batch_dev(in_dev, out_dev, ntracks, nch, n, sr, settings, mode, results, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
+                     float* const* out, wam_result* results) {
+  if (!in || !out || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
+  int rc = ensure_device(); if (rc) return rc;
+  const size_t per = (size_t)nch * (size_t)(n > 0 ? n : 1);
+  const int group = 64;                               // host staging group
+  DevBuf din, dout;
+  rc = din.alloc(sizeof(float) * per * group); if (rc) return rc;
+  rc = dout.alloc(sizeof(float) * per * group); if (rc) return rc;
+  for (int t0 = 0; t0 < ntracks; t0 += group) {
+    const int g = ntracks - t0 < group ? ntracks - t0 : group;
+    for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
+      WAM_HIP(hipMemcpyAsync(din.as<float>() + ((size_t)t * nch + c) * n, in[(size_t)(t0 + t) * nch + c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, nullptr));
+    rc = render_batch_dev(din.as<float>(), dout.as<float>(), g, nch, n, sr, settings, mode, results ? results + t0 : nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
+      WAM_HIP(hipMemcpyAsync(out[(size_t)(t0 + t) * nch + c], dout.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, nullptr));
+    WAM_HIP(hipStreamSynchronize(nullptr));
+  }
+  return WAM_OK;
+}
 
 int wam_stereo(const float* const* ch, int64_t n, double sr, double width, int bass_mono, double bass_freq, float* const* out) {
   FrontPlan fp;

@@ -35,6 +35,53 @@ __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in
   meter_finish(m, lds, peaks + chan);
 }
 
+// x * gain -> out (optional), metered.  One workgroup per (track, channel).  gains: per track or NULL.
+__global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
+                                                         const double* __restrict__ gains, const MeterPlan* __restrict__ plan,
+                                                         double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks) {
+  __shared__ double lds[kMeterLds];
+  __shared__ float ctx[kCtxFloats];
+  const MeterPlan& pl = *plan;
+  const int64_t chan = blockIdx.x;
+  const double G = gains ? gains[chan / nch] : 1.0;
+  const float* x = in + chan * n;
+  float* y = out ? out + chan * n : nullptr;
+  MeterState m;
+  meter_init(m, pl, 0);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_base = t * kTile;
+    const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    float v[C], xp[3];
+    load_chunk(x, n, base, v);
+    if (gains) {
+#pragma unroll
+      for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * G);       // normalizer.js:66-72
+    }
+    if (y) store_chunk(y, n, base, v);
+    const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
+    prev_ctx<3>(last, xp, ctx, (int)(t & 1), t == 0);
+    meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hopsums + chan * hop_stride);
+  }
+  meter_finish(m, lds, peaks + chan);
+}
+
+// Stage-8 gain per track from the gated loudness (normalizer.js:39-51).  gains[t] = 1 when
+// the loudness is not finite (silence: the reference returns its input) or normalisation is off.
+__global__ void k_norm_gain(const GateOut* __restrict__ gate, const MeterPlan* __restrict__ plan, int ntracks, double target,
+                            double* __restrict__ gains, double* __restrict__ lufs_in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntracks) return;
+  const MeterPlan& pl = *plan;
+  const GateOut g = gate[t];
+  double lufs;
+  if (pl.too_short) lufs = target;                                     // measureLUFS(buffer, targetLUFS) fallback
+  else if (g.nblocks == 0 || g.c1 == 0 || g.c2 == 0) lufs = -INFINITY;
+  else lufs = -0.691 + 10 * log10(g.mean2);
+  lufs_in[t] = lufs;
+  gains[t] = isfinite(lufs) ? pow(10.0, (target - lufs) / 20) : 1.0;
+}
+
 // Gating (lufs.js:57-81).  blocks: scratch [ntracks][nblocks] (always written).
 __global__ __launch_bounds__(256) void k_gate(const double* __restrict__ hopsums, int64_t hop_stride, const double* __restrict__ peaks,
                                               const MeterPlan* __restrict__ plan, double* __restrict__ blocks, uint8_t* __restrict__ mask,
@@ -145,6 +192,22 @@ void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void*
 
 int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream) {
   WAM_LAUNCH("k_gate", k_gate, dim3(ntracks), dim3(256), stream, s.hopsums, s.hop_stride, s.peaks, s.plan, s.blocks, s.mask, s.gate);
+  return WAM_OK;
+}
+
+int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_t n, const double* gains, const MeterPlan& pl,
+                       const MeterScratch& s, hipStream_t stream) {
+  WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
+  if (n > 0) {
+    WAM_LAUNCH("k_gain_meter", k_gain_meter, dim3(ntracks * nch), dim3(kThreads), stream, in, out, nch, n, gains, (const MeterPlan*)s.plan, s.hopsums, s.hop_stride, s.peaks);
+  } else {
+    WAM_HIP(hipMemsetAsync(s.peaks, 0, sizeof(double) * (size_t)ntracks * nch, stream));
+  }
+  return enqueue_gate(pl, ntracks, s, stream);
+}
+
+int enqueue_norm_gain(const MeterScratch& s, int ntracks, double target, double* gains, double* lufs_in, hipStream_t stream) {
+  WAM_LAUNCH("k_norm_gain", k_norm_gain, dim3((ntracks + 63) / 64), dim3(64), stream, (const GateOut*)s.gate, (const MeterPlan*)s.plan, ntracks, target, gains, lufs_in);
   return WAM_OK;
 }
 
