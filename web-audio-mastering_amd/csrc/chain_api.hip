@@ -427,6 +427,15 @@ static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int 
   return st.down(st.out.as<float>(), out, nullptr);
 }
 
+int wam_deharsh(const float* const* ch, int nch, int64_t n, double sr, float* const* out) {
+  int rc = check_io(ch, nch, n, out); if (rc) return rc;
+  if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
+  rc = enqueue_deharsh(st.in.as<float>(), st.out.as<float>(), 1, nch, n, sr, 1.0, nullptr); if (rc) return rc;
+  return st.down(st.out.as<float>(), out, nullptr);
+}
+
 int wam_exciter(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 0, out); }
 int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 1, out); }
 int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 2, out); }
