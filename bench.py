@@ -42,7 +42,19 @@ SYNTH = dict(amp=1.6, dc=0.0, clickAmp=0.6)
 
 # algorithmic bytes per sample-channel of each kernel (DESIGN.md "Kernels")
 KERNEL_BYTES = {
-    "k_meter": 4,
+    "k_meter": 4,          # read x
+    "k_gain_meter": 8,     # read x, write x*G
+    "k_dh_bands": 4,       # read x (the 4x frame overlap is served by L2)
+    "k_dh_apply": 8,       # read x, write y
+    "k_exciter": 8,
+    "k_win_peak": 4,
+    "k_warm_punch": 8,
+    "k_front": 8,
+    "k_sc_env": 6,         # read x (4), write the shared gain envelope (4 per frame = 2 per sample-channel)
+    "k_sc_apply": 10,      # read x + envelope, write y
+    "k_lim_tm": 6,         # read x, write transient map
+    "k_lim_gain": 8,       # read x + transient map, write gain envelope
+    "k_lim_apply": 10,     # read x + envelope, write y
 }
 
 
