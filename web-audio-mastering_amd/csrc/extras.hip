@@ -1,0 +1,326 @@
+// extras.hip - the callers and data formats either side of the chain:
+//   wam_dc_offset     detectDCOffsetBuffer / removeDCOffset          web/lib/dsp/dc-offset.js:13-77
+//   wam_normalize     normalizeChannelsToLUFS (NORMALIZE message)    web/workers/dsp-worker.js:457-527
+//   wam_encode_pcm24  encodeWAV 24-bit sample loop                   web/ui/encoder.js:92-124
+//   wam_wav_header    encodeWAV header                               web/ui/encoder.js:74-86
+//   wam_stft_db       Spectrogram.process / fft / updateLatestColumn web/ui/spectrogram.js:113-257, batched over frames
+#include "chain.hpp"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace wam {
+
+// ------------------------------------------------------------------ DC offset
+// partial sums: 256 blocks per channel, fixed order -> deterministic
+__global__ __launch_bounds__(256) void k_dc_partial(const float* __restrict__ in, int64_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t chan = blockIdx.y;
+  const float* x = in + chan * n;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t st = (int64_t)blockIdx.x * per;
+  int64_t en = st + per; if (en > n) en = n;
+  double s = 0;
+  for (int64_t i = st + threadIdx.x; i < en; i += 256) s += (double)x[i];
+  s = wave_sum_ordered(s);
+  if (lane_id() == 0) red[wave_id()] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[chan * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void k_dc_final(const double* __restrict__ part, int nparts, int64_t n, double* __restrict__ dc) {
+  const int chan = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double s = 0;
+  for (int i = 0; i < nparts; i++) s += part[chan * nparts + i];
+  dc[chan] = s / (double)n;
+}
+__global__ __launch_bounds__(256) void k_dc_sub(const float* __restrict__ in, float* __restrict__ out, int64_t n, const double* __restrict__ dc) {
+  const int64_t chan = blockIdx.y;
+  const double d = dc[chan];
+  const bool sub = fabs(d) > 1e-10;                                  // dc-offset.js:70
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = in[chan * n + i];
+    out[chan * n + i] = sub ? f32r((double)v - d) : v;
+  }
+}
+
+// ------------------------------------------------------------------ 24-bit PCM
+__device__ __forceinline__ int32_t quant24(float s) {
+  double v = s;
+  if (!(v == v)) return 0;                                            // NaN ends up as 0 through `& 0xFF`
+  v = fmax(-1.0, fmin(1.0, v));
+  const double r = floor(v * 8388607.0 + 0.5);                        // Math.round: half toward +inf
+  return (int32_t)fmax(-8388607.0, fmin(8388607.0, r));
+}
+// 12 output bytes (3 dwords) per thread: 2 stereo frames or 4 mono frames
+__global__ __launch_bounds__(256) void k_pcm24(const float* __restrict__ in, int nch, int64_t n, uint8_t* __restrict__ out) {
+  const int fpt = 4 / nch;                                            // frames per thread
+  const int64_t groups = (n + fpt - 1) / fpt;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+    uint32_t w[4];
+    bool full = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t f = g * fpt + k / nch;
+      const int c = k % nch;
+      if (f < n) w[k] = (uint32_t)quant24(in[(int64_t)c * n + f]) & 0xFFFFFFu; else { w[k] = 0; full = false; }
+    }
+    uint8_t* o = out + g * 12;
+    if (full) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+      o32[0] = w[0] | (w[1] << 24);
+      o32[1] = (w[1] >> 8) | (w[2] << 16);
+      o32[2] = (w[2] >> 16) | (w[3] << 8);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t f = g * fpt + k / nch;
+        if (f < n) { o[3 * k] = w[k] & 0xFF; o[3 * k + 1] = (w[k] >> 8) & 0xFF; o[3 * k + 2] = (w[k] >> 16) & 0xFF; }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ spectrogram STFT
+struct StftRow { int bin1, bin2; double frac; int valid; };
+__global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int nch, int64_t n, int nfft, int bits, int hop, int64_t nframes,
+                                              const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
+                                              double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols) {
+  extern __shared__ float sm[];
+  float* re = sm; float* im = sm + nfft; float* sp = sm + 2 * nfft;
+  const int half = nfft >> 1;
+  for (int64_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+    const int64_t pos = f * hop;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfft; i += 256) {
+      float m;
+      if (nch >= 2) m = f32r(0.5 * ((double)in[pos + i] + (double)in[n + pos + i])); else m = in[pos + i];
+      const unsigned r = __brev((unsigned)i) >> (32 - bits);
+      re[r] = f32r((double)m * (double)win[i]);                       // spectrogram.js:121-123, bit reversal :222-235
+      im[r] = 0.0f;
+    }
+    __syncthreads();
+    for (int size = 2; size <= nfft; size <<= 1) {                    // spectrogram.js:238-256, f32 store after every butterfly
+      const int hs = size >> 1, step = nfft / size;
+      for (int b = threadIdx.x; b < half; b += 256) {
+        const int k = b % hs, j = (b / hs) * size + k;
+        const double cw = cosT[k * step], sw = sinT[k * step];
+        const double xr = re[j + hs], xi = im[j + hs];
+        const double tr = xr * cw - xi * sw;
+        const double ti = xr * sw + xi * cw;
+        const double ar = re[j], ai = im[j];
+        re[j + hs] = f32r(ar - tr); im[j + hs] = f32r(ai - ti);
+        re[j] = f32r(ar + tr); im[j] = f32r(ai + ti);
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < half; i += 256) {
+      const double pw = (double)re[i] * (double)re[i] + (double)im[i] * (double)im[i];
+      const double db = 10 * log10(pw + 1e-24) + add_db;              // spectrogram.js:135-141
+      const float v = f32r(db < -144 ? -144.0 : db);
+      sp[i] = v;
+      out_db[f * half + i] = v;
+    }
+    if (cols) {
+      __syncthreads();
+      for (int yy = threadIdx.x; yy < 256; yy += 256) {
+        const StftRow r = rows[yy];
+        double v = -144;
+        if (r.valid) v = (double)sp[r.bin1] + ((double)sp[r.bin2] - (double)sp[r.bin1]) * r.frac;   // spectrogram.js:196-200
+        cols[f * 256 + yy] = f32r(v);
+      }
+    }
+  }
+}
+
+static int check_in(const float* const* ch, int nch, int64_t n) {
+  if (!ch || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
+  for (int c = 0; c < nch; c++) if (!ch[c] && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
+static int upload_chans(const float* const* ch, int nch, int64_t n, DevBuf& b) {
+  int rc = b.alloc(sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
+  for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpyAsync(b.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, nullptr));
+  return WAM_OK;
+}
+
+}  // namespace wam
+
+using namespace wam;
+
+extern "C" {
+
+int wam_dc_offset(const float* const* ch, int nch, int64_t n, double* dc, int remove, float* const* out) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!dc || (remove && !out)) { set_error("dc / out is NULL"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  if (n == 0) { for (int c = 0; c < nch; c++) dc[c] = NAN; return WAM_OK; }     // 0 / 0 in the reference
+  DevBuf in, o, part, dcd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  const int nparts = 256;
+  rc = part.alloc(sizeof(double) * nparts * nch); if (rc) return rc;
+  rc = dcd.alloc(sizeof(double) * nch); if (rc) return rc;
+  WAM_LAUNCH("k_dc_partial", k_dc_partial, dim3(nparts, nch), dim3(256), nullptr, (const float*)in.as<float>(), n, part.as<double>());
+  WAM_LAUNCH("k_dc_final", k_dc_final, dim3(nch), dim3(64), nullptr, (const double*)part.as<double>(), nparts, n, dcd.as<double>());
+  if (remove) {
+    rc = o.alloc(sizeof(float) * (size_t)nch * (size_t)n); if (rc) return rc;
+    int64_t bx = (n + 255) / 256; if (bx > 2048) bx = 2048;
+    WAM_LAUNCH("k_dc_sub", k_dc_sub, dim3((unsigned)bx, nch), dim3(256), nullptr, (const float*)in.as<float>(), o.as<float>(), n, (const double*)dcd.as<double>());
+    for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpyAsync(out[c], o.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, nullptr));
+  }
+  WAM_HIP(hipMemcpyAsync(dc, dcd.p, sizeof(double) * nch, hipMemcpyDeviceToHost, nullptr));
+  WAM_HIP(hipStreamSynchronize(nullptr));
+  return WAM_OK;
+}
+
+int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double target_lufs, double ceiling_db, float* const* out,
+                  wam_normalize_result* res) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out || !res || !(sr > 0)) { set_error("invalid normalize arguments"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  std::memset(res, 0, sizeof(*res));
+  MeterPlan mp; rc = make_meter_plan(nch, n, sr, target_lufs, &mp); if (rc) return rc;      // measure with fallback = target (:460)
+  MeterPlan mp14 = mp; mp14.fallback = -14.0;                                                 // final measurements use the default (:504,:517)
+  DevBuf in, tmp, o, ms, ms2, gd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  rc = ms.alloc(meter_scratch_bytes(mp, 1, false)); if (rc) return rc;
+  MeterScratch M; carve_meter_scratch(mp, 1, false, ms.p, &M);
+  rc = enqueue_meter(in.as<float>(), 1, mp, n, M, nullptr); if (rc) return rc;
+  GateOut g;
+  WAM_HIP(hipMemcpy(&g, M.gate, sizeof(g), hipMemcpyDeviceToHost));
+  const double cur = finish_lufs(mp, g), pk = finish_peak_db(g);
+  res->current_lufs = cur;
+  const size_t bytes = sizeof(float) * (size_t)(n > 0 ? n : 1);
+  if (!std::isfinite(cur)) {                                                                  // :466-469
+    for (int c = 0; c < nch && n > 0; c++) std::memcpy(out[c], ch[c], sizeof(float) * (size_t)n);
+    res->final_lufs = cur; res->peak_db = pk; res->measured = 0;
+    return WAM_OK;
+  }
+  res->measured = 1;
+  const double gdb = target_lufs - cur;                                                       // :473-476
+  const double gl = std::pow(10, gdb / 20);
+  const double proj = pk + gdb;
+  res->gain_applied_db = gdb;
+  rc = tmp.alloc(bytes * nch); if (rc) return rc;
+  rc = gd.alloc(sizeof(double)); if (rc) return rc;
+  WAM_HIP(hipMemcpy(gd.p, &gl, sizeof(double), hipMemcpyHostToDevice));
+  rc = ms2.alloc(meter_scratch_bytes(mp14, 1, false)); if (rc) return rc;
+  MeterScratch M2; carve_meter_scratch(mp14, 1, false, ms2.p, &M2);
+  WAM_HIP(hipMemcpyAsync(M2.plan, &mp14, sizeof(mp14), hipMemcpyHostToDevice, nullptr));
+  const float* result = tmp.as<float>();
+  if (proj > ceiling_db) {                                                                    // :490-515
+    LimiterPlan lp; rc = make_limiter_plan(sr, std::pow(10, ceiling_db / 20), 3, 100, 3, 1, &lp); if (rc) return rc;
+    DevBuf plan, tmb, gv;
+    rc = plan.alloc(sizeof(lp)); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(plan.p, &lp, sizeof(lp), hipMemcpyHostToDevice, nullptr));
+    rc = tmb.alloc(bytes); if (rc) return rc;
+    rc = gv.alloc(bytes); if (rc) return rc;
+    rc = o.alloc(bytes * nch); if (rc) return rc;
+    rc = enqueue_gain_meter(in.as<float>(), tmp.as<float>(), 1, nch, n, gd.as<double>(), mp14, M2, nullptr); if (rc) return rc;
+    WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, nullptr));
+    rc = enqueue_limiter(tmp.as<float>(), o.as<float>(), tmb.as<float>(), gv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), 1,
+                         M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, nullptr); if (rc) return rc;
+    rc = enqueue_gate(mp14, 1, M2, nullptr); if (rc) return rc;
+    WAM_HIP(hipMemcpy(&g, M2.gate, sizeof(g), hipMemcpyDeviceToHost));
+    res->peak_db = finish_peak_db(g);
+    res->final_lufs = finish_lufs(mp14, g);
+    res->limiter_applied = 1;
+    result = o.as<float>();
+    for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpy(out[c], result + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return WAM_OK;
+  }
+  rc = enqueue_gain_meter(in.as<float>(), tmp.as<float>(), 1, nch, n, gd.as<double>(), mp14, M2, nullptr); if (rc) return rc;
+  WAM_HIP(hipMemcpy(&g, M2.gate, sizeof(g), hipMemcpyDeviceToHost));
+  res->final_lufs = finish_lufs(mp14, g);
+  res->peak_db = proj;
+  for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpy(out[c], result + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
+int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out) { set_error("out is NULL"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  if (n == 0) return WAM_OK;
+  DevBuf in, o;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  const size_t obytes = (size_t)3 * nch * (size_t)n;
+  rc = o.alloc(obytes + 16); if (rc) return rc;
+  const int fpt = 4 / nch;
+  const int64_t groups = (n + fpt - 1) / fpt;
+  int64_t bx = (groups + 255) / 256; if (bx > 4096) bx = 4096;
+  WAM_LAUNCH("k_pcm24", k_pcm24, dim3((unsigned)bx), dim3(256), nullptr, (const float*)in.as<float>(), nch, n, o.as<uint8_t>());
+  WAM_HIP(hipMemcpy(out, o.p, obytes, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
+int wam_wav_header(int nch, int64_t n, int sample_rate, int bits, uint8_t h[44]) {
+  if (!h || nch < 1 || n < 0 || (bits != 16 && bits != 24)) { set_error("invalid header arguments"); return WAM_ERR_INVALID; }
+  const uint32_t bps = (uint32_t)bits / 8, data = (uint32_t)((uint64_t)n * nch * bps);
+  std::memcpy(h, "RIFF", 4); uint32_t v = 36 + data; std::memcpy(h + 4, &v, 4);
+  std::memcpy(h + 8, "WAVEfmt ", 8); v = 16; std::memcpy(h + 16, &v, 4);
+  uint16_t s = 1; std::memcpy(h + 20, &s, 2); s = (uint16_t)nch; std::memcpy(h + 22, &s, 2);
+  v = (uint32_t)sample_rate; std::memcpy(h + 24, &v, 4); v = (uint32_t)sample_rate * nch * bps; std::memcpy(h + 28, &v, 4);
+  s = (uint16_t)(nch * bps); std::memcpy(h + 32, &s, 2); s = (uint16_t)bits; std::memcpy(h + 34, &s, 2);
+  std::memcpy(h + 36, "data", 4); std::memcpy(h + 40, &data, 4);
+  return WAM_OK;
+}
+
+int64_t wam_stft_num_frames(int64_t n, int nfft, int hop) {
+  if (nfft <= 0 || hop <= 0 || n < nfft) return 0;
+  return (n - nfft) / hop + 1;
+}
+
+int wam_stft_db(const float* const* ch, int nch, int64_t n, double sr, int nfft, int hop, float* out_db, float* columns) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out_db || nfft < 16 || nfft > 8192 || (nfft & (nfft - 1)) || hop < 1 || !(sr > 0)) { set_error("invalid STFT arguments (nfft must be a power of two in 16..8192)"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  const int64_t nframes = wam_stft_num_frames(n, nfft, hop);
+  if (nframes == 0) return WAM_OK;
+  int bits = 0; while ((1 << bits) < nfft) bits++;
+  const int half = nfft >> 1;
+  std::vector<float> ct(nfft), stb(nfft), win(nfft);
+  for (int i = 0; i < nfft; i++) {                                       // spectrogram.js:40-48
+    const double ang = -2 * M_PI * i / nfft;
+    stb[i] = (float)std::sin(ang); ct[i] = (float)std::cos(ang);
+    win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / nfft)));
+  }
+  std::vector<StftRow> rows(256);
+  {
+    const double lmin = std::log10(20.0), lmax = std::log10(22000.0), lr = lmax - lmin, nyq = sr / 2;   // spectrogram.js:177-203
+    for (int y = 0; y < 256; y++) {
+      const double fr = std::pow(10, lmax - ((double)y / 255) * lr);
+      StftRow r{0, 0, 0.0, 0};
+      if (fr >= 20 && fr <= nyq) {
+        const double bf = (fr * nfft) / sr;
+        const int b1 = (int)std::floor(bf);
+        if (b1 < half) { r.bin1 = b1; r.bin2 = b1 + 1 < half ? b1 + 1 : b1; r.frac = bf - b1; r.valid = 1; }
+      }
+      rows[y] = r;
+    }
+  }
+  const double add_db = 10 * std::log10(16.0) + (-20 * std::log10((double)nfft));   // correctionAC + fftNorm, :135-136
+  DevBuf in, tabs, rowsd, od, cd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  rc = tabs.alloc(sizeof(float) * 3 * nfft); if (rc) return rc;
+  WAM_HIP(hipMemcpyAsync(tabs.as<float>(), ct.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
+  WAM_HIP(hipMemcpyAsync(tabs.as<float>() + nfft, stb.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
+  WAM_HIP(hipMemcpyAsync(tabs.as<float>() + 2 * nfft, win.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
+  rc = rowsd.alloc(sizeof(StftRow) * 256); if (rc) return rc;
+  WAM_HIP(hipMemcpyAsync(rowsd.p, rows.data(), sizeof(StftRow) * 256, hipMemcpyHostToDevice, nullptr));
+  rc = od.alloc(sizeof(float) * (size_t)nframes * half); if (rc) return rc;
+  if (columns) { rc = cd.alloc(sizeof(float) * (size_t)nframes * 256); if (rc) return rc; }
+  int64_t bx = nframes < 4096 ? nframes : 4096;
+  const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
+  prof_begin("k_stft", nullptr);
+  hipLaunchKernelGGL(k_stft, dim3((unsigned)bx), dim3(256), shmem, nullptr, (const float*)in.as<float>(), nch, n, nfft, bits, hop, nframes,
+                     (const float*)tabs.as<float>(), (const float*)(tabs.as<float>() + nfft), (const float*)(tabs.as<float>() + 2 * nfft),
+                     add_db, od.as<float>(), (const StftRow*)rowsd.as<StftRow>(), columns ? cd.as<float>() : nullptr);
+  prof_end(nullptr);
+  WAM_HIP(hipGetLastError());
+  WAM_HIP(hipMemcpy(out_db, od.p, sizeof(float) * (size_t)nframes * half, hipMemcpyDeviceToHost));
+  if (columns) WAM_HIP(hipMemcpy(columns, cd.p, sizeof(float) * (size_t)nframes * 256, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
+}  // extern "C"
