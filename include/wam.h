@@ -131,6 +131,9 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
                         double fallback, double* lufs, double* dbtp, void* stream);
 
+/* applyGain(audioBuffer, gainDB), web/lib/dsp/normalizer.js:103-121: out = f32(in * 10^(gainDB/20)). */
+int wam_apply_gain(const float* const* ch, int nch, int64_t n, double gain_db, float* const* out);
+
 /* normalizeChannelsToLUFS, dsp-worker.js:457-527 (message NORMALIZE :1367;
  * DSPWorkerInterface.normalize(), worker-interface.js:197).  Applies the limiter
  * when the projected peak exceeds ceiling_db. */

@@ -3,6 +3,7 @@
 // path here: every compute entry point needs a HIP device.
 #include "meter_host.hpp"
 #include "../../include/wam_synth.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <cmath>
@@ -13,6 +14,7 @@ namespace wam {
 
 static thread_local std::string g_err;
 static thread_local int g_device = -1;
+static std::atomic<int> g_default_device{-1};   // set by the first wam_init; threads that never called wam_init use it
 
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -45,7 +47,8 @@ int ensure_device() {
     if (hipSetDevice(g_device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g_device); return WAM_ERR_NO_DEVICE; }
     return WAM_OK;
   }
-  return wam_init(0);
+  const int d = g_default_device.load();
+  return wam_init(d >= 0 ? d : 0);
 }
 
 static int check_audio(const float* const* ch, int nch, int64_t n) {
@@ -135,6 +138,8 @@ int wam_init(int device) {
   if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return WAM_ERR_INVALID; }
   if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
   g_device = device;
+  int expect = -1;
+  g_default_device.compare_exchange_strong(expect, device);
   return WAM_OK;
 }
 

@@ -237,6 +237,26 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
   return WAM_OK;
 }
 
+int wam_apply_gain(const float* const* ch, int nch, int64_t n, double gain_db, float* const* out) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out) { set_error("out is NULL"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  if (n == 0) return WAM_OK;
+  MeterPlan mp; rc = make_meter_plan(nch, n, 48000.0, -14.0, &mp); if (rc) return rc;     // the metering by-product is discarded
+  DevBuf in, o, ms, gd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  rc = o.alloc(sizeof(float) * (size_t)nch * (size_t)n); if (rc) return rc;
+  rc = ms.alloc(meter_scratch_bytes(mp, 1, false)); if (rc) return rc;
+  MeterScratch M; carve_meter_scratch(mp, 1, false, ms.p, &M);
+  WAM_HIP(hipMemcpyAsync(M.plan, &mp, sizeof(mp), hipMemcpyHostToDevice, nullptr));
+  const double gl = std::pow(10, gain_db / 20);                                            // normalizer.js:104
+  rc = gd.alloc(sizeof(double)); if (rc) return rc;
+  WAM_HIP(hipMemcpy(gd.p, &gl, sizeof(double), hipMemcpyHostToDevice));
+  rc = enqueue_gain_meter(in.as<float>(), o.as<float>(), 1, nch, n, gd.as<double>(), mp, M, nullptr); if (rc) return rc;
+  for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpy(out[c], o.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
 int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out) {
   int rc = check_in(ch, nch, n); if (rc) return rc;
   if (!out) { set_error("out is NULL"); return WAM_ERR_INVALID; }

@@ -1,0 +1,194 @@
+// index.mjs - drop-in JavaScript surface of the MI355X mastering backend.
+//
+// Same names, argument meaning and error behaviour as the reference's JavaScript:
+//   - the sync library functions of web/lib/dsp/index.js (measureLUFS, findTruePeak,
+//     normalizeToLUFS, applyGain, applyLookaheadLimiter, applyMasteringSoftClip,
+//     applyFinalFilters, processHybridDynamic, applyExciter, applyTapeWarmth,
+//     applyMultibandTransient, detectDCOffsetBuffer, removeDCOffset) and encodeWAV
+//     (web/ui/encoder.js:51);
+//   - the promise API of web/workers/worker-interface.js (DSPWorkerInterface,
+//     getDSPWorker, initDSPWorker).
+// Everything below is argument marshalling; the arithmetic runs in libwam_hip.so through
+// the N-API addon (../napi/wam.node).  There is no JavaScript fallback: without the addon
+// or a HIP device the calls throw / reject.
+import { createRequire } from 'module';
+import { fileURLToPath } from 'url';
+import path from 'path';
+
+const require = createRequire(import.meta.url);
+const here = path.dirname(fileURLToPath(import.meta.url));
+let native = null;
+function addon() {
+  if (!native) {
+    try { native = require(path.join(here, '..', 'napi', 'wam.node')); }
+    catch (e) { throw new Error(`wam: native addon not available (${e.message}); there is no JavaScript fallback`); }
+  }
+  return native;
+}
+
+// AudioBuffer-like container, same shape as WorkerAudioBuffer (web/workers/dsp-worker.js:36-61)
+export class WamAudioBuffer {
+  constructor({ numberOfChannels, length, sampleRate }) {
+    this.numberOfChannels = numberOfChannels;
+    this.length = length;
+    this.sampleRate = sampleRate;
+    this.duration = length / sampleRate;
+    this._channels = [];
+    for (let i = 0; i < numberOfChannels; i++) this._channels.push(new Float32Array(length));
+  }
+  getChannelData(c) { return this._channels[c]; }
+  copyToChannel(source, c, start = 0) { this._channels[c].set(source, start); }
+  copyFromChannel(dest, c, start = 0) { dest.set(this._channels[c].subarray(start, start + dest.length)); }
+}
+
+function chansOf(ab) { const r = []; for (let c = 0; c < ab.numberOfChannels; c++) r.push(ab.getChannelData(c)); return r; }
+function makeAB(channels, sampleRate) {
+  const Ctor = (typeof globalThis.AudioBuffer === 'function') ? globalThis.AudioBuffer : WamAudioBuffer;
+  const ab = new Ctor({ numberOfChannels: channels.length, length: channels[0].length, sampleRate });
+  channels.forEach((c, i) => ab.copyToChannel(c, i));
+  return ab;
+}
+const stage = (name, ab, params = []) => makeAB(addon().stageSync(name, chansOf(ab), ab.sampleRate, params), ab.sampleRate);
+
+// ---- web/lib/dsp/index.js ---------------------------------------------------------------
+export function measureLUFS(audioBuffer, fallbackLufs = -14) {                       // lufs.js:17
+  return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate, fallbackLufs).lufs;
+}
+export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
+  return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
+}
+export function applyGain(audioBuffer, gainDB) { return stage('gain', audioBuffer, [gainDB]); }   // normalizer.js:103
+export function normalizeToLUFS(audioBuffer, targetLUFS = -14, ceilingDB = -1, options = {}) {    // normalizer.js:38
+  const { lufs, peakDB } = addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate, targetLUFS);
+  if (!isFinite(lufs)) return audioBuffer;                    // the reference returns the SAME object
+  const gainDB = targetLUFS - lufs;
+  const gained = applyGain(audioBuffer, gainDB);
+  if (options.skipLimiter) return gained;
+  if (peakDB + gainDB > ceilingDB) return applyLookaheadLimiter(gained, Math.pow(10, ceilingDB / 20), 3, 100);
+  return gained;
+}
+export function applyLookaheadLimiter(audioBuffer, ceilingLinear = 0.891, lookaheadMs = 3, releaseMs = 100, kneeDB = 3, preserveTransients = true) {
+  // the worker twin (dsp-worker.js:286); the lib twin differs in one seed value (SURVEY.md 0.4)
+  return stage('limiter', audioBuffer, [ceilingLinear, lookaheadMs, releaseMs, kneeDB, preserveTransients ? 1 : 0]);
+}
+export function applyMasteringSoftClip(audioBuffer, options = {}) {                  // soft-clipper.js:165
+  const { ceiling = -1, lookaheadMs = 0.5, releaseMs = 10, drive = 1.5 } = options;
+  return stage('softClip', audioBuffer, [ceiling, lookaheadMs, releaseMs, drive]);
+}
+export function applyFinalFilters(audioBuffer, options = {}) {                       // final-filters.js:96
+  const { highpass = true, lowpass = true } = options;
+  return stage('finalFilters', audioBuffer, [highpass ? 1 : 0, lowpass ? 1 : 0]);
+}
+export function processHybridDynamic(audioBuffer, preset = 'gentle') {               // dynamic-processor.js:595
+  if (preset !== 'mastering') throw new Error(`wam: only the 'mastering' preset (the export chain's) is implemented, got '${preset}'`);
+  return stage('deharsh', audioBuffer);
+}
+export function applyExciter(audioBuffer) { return stage('exciter', audioBuffer); }                     // exciter.js:223
+export function applyTapeWarmth(audioBuffer) { return stage('tapeWarmth', audioBuffer); }               // multiband-saturation.js:365
+export function applyMultibandTransient(audioBuffer) { return stage('multibandTransient', audioBuffer); } // multiband-transient.js:15
+export function detectDCOffsetBuffer(audioBuffer) {                                  // dc-offset.js:38
+  const results = [];
+  let total = 0;
+  for (let c = 0; c < audioBuffer.numberOfChannels; c++) {
+    const mean = addon().dcOffset([audioBuffer.getChannelData(c)]).dc[0];
+    const abs = Math.abs(mean);
+    results.push({ linear: mean, dB: abs > 0 ? 20 * Math.log10(abs) : -Infinity, percent: abs * 100, significant: abs > 0.001 });
+    total += abs;
+  }
+  const avg = total / audioBuffer.numberOfChannels;
+  return { channels: results, average: { linear: avg, dB: avg > 0 ? 20 * Math.log10(avg) : -Infinity, percent: avg * 100 },
+    significant: results.some(r => r.significant) };
+}
+export function removeDCOffset(channel) {                                            // dc-offset.js:67 (in place, returns the offset)
+  const r = addon().dcOffset([channel], true);
+  channel.set(r.channels[0]);
+  return r.dc[0];
+}
+
+// encodeWAV(audioBuffer, targetSampleRate, bitDepth, options) - web/ui/encoder.js:51.  24-bit only: the 16-bit
+// paths draw their dither from Math.random (encoder.js:13) and stay with the caller (SURVEY.md 8f rank 3).
+export function encodeWAV(audioBuffer, targetSampleRate, bitDepth, options = {}) {
+  if (bitDepth !== 24) throw new Error('wam: encodeWAV implements the 24-bit branch only');
+  const n = audioBuffer.length, nch = audioBuffer.numberOfChannels;
+  const sampleRate = targetSampleRate || audioBuffer.sampleRate;
+  const pcm = addon().encodePcm24(chansOf(audioBuffer));
+  const out = new Uint8Array(44 + pcm.length);
+  const v = new DataView(out.buffer);
+  const ws = (o, s) => { for (let i = 0; i < s.length; i++) v.setUint8(o + i, s.charCodeAt(i)); };
+  ws(0, 'RIFF'); v.setUint32(4, 36 + pcm.length, true); ws(8, 'WAVE'); ws(12, 'fmt '); v.setUint32(16, 16, true);
+  v.setUint16(20, 1, true); v.setUint16(22, nch, true); v.setUint32(24, sampleRate, true); v.setUint32(28, sampleRate * nch * 3, true);
+  v.setUint16(32, nch * 3, true); v.setUint16(34, 24, true); ws(36, 'data'); v.setUint32(40, pcm.length, true);
+  out.set(pcm, 44);
+  return out;
+}
+export async function encodeWAVAsync(audioBuffer, targetSampleRate, bitDepth, options = {}) {   // encoder.js:143
+  const { onProgress = null, shouldCancel = null } = options || {};
+  if (shouldCancel && shouldCancel()) throw new Error('Cancelled');
+  const r = encodeWAV(audioBuffer, targetSampleRate, bitDepth, options);
+  if (onProgress) onProgress(1);
+  return r;
+}
+export function stftDb(audioBuffer, nfft = 4096, hop = 1024) {                       // spectrogram.js:113-143, batched
+  return addon().stftDb(chansOf(audioBuffer), audioBuffer.sampleRate, nfft, hop);
+}
+
+// ---- web/workers/worker-interface.js ------------------------------------------------------
+export class DSPWorkerInterface {
+  constructor() { this.worker = null; this.pending = new Map(); this.nextId = 0; this.isReady = false; this._tail = Promise.resolve(); }
+  async init(device = 0) {                                                           // worker-interface.js:23
+    if (this.worker) return;
+    addon().init(device);
+    this.worker = addon();
+    this.isReady = true;
+  }
+  // one request at a time, FIFO, like the single worker thread (worker-interface.js:93-109)
+  _send(run) {
+    if (!this.worker) return Promise.reject(new Error('Worker not initialized. Call init() first.'));
+    return new Promise((resolve, reject) => {
+      const id = this.nextId++;
+      this.pending.set(id, { resolve, reject });
+      const settle = (fn) => (v) => { if (this.pending.has(id)) { this.pending.delete(id); fn(v); } };
+      this._tail = this._tail.then(() => this.pending.has(id) ? run().then(settle(resolve), settle(reject)) : undefined);
+    });
+  }
+  async measureLUFS(audioBuffer) {                                                   // :162
+    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const r = await this._send(() => addon().meter(ch, sr, -14));
+    return { lufs: r.lufs };
+  }
+  async findTruePeak(audioBuffer) {                                                  // :178
+    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const r = await this._send(() => addon().meter(ch, sr, -14));
+    return { peakDB: r.peakDB };
+  }
+  async normalize(audioBuffer, targetLUFS = -14, ceilingDB = -1, onProgress = null) {   // :197
+    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const r = await this._send(() => addon().normalize(ch, sr, targetLUFS, ceilingDB));
+    if (onProgress) onProgress(1.0, 'Complete');
+    return { audioBuffer: makeAB(r.channels, sr), currentLUFS: r.currentLUFS, finalLUFS: r.finalLUFS, peakDB: r.peakDB,
+      gainApplied: r.gainApplied, limiterApplied: r.limiterApplied };
+  }
+  async applyLimiter(audioBuffer, options = {}, onProgress = null) {                 // :227, defaults dsp-worker.js:1385-1389
+    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const p = [options.ceilingLinear || 0.891, options.lookaheadMs || 3, options.releaseMs || 100, options.kneeDB || 3,
+      options.preserveTransients !== false ? 1 : 0];
+    const out = await this._send(() => addon().stage('limiter', ch, sr, p));
+    if (onProgress) onProgress(1.0, 'Complete');
+    return { audioBuffer: makeAB(out, sr) };
+  }
+  async renderFullChain(audioBuffer, settings, mode = 'preview', onProgress = null) {  // :259
+    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const r = await this._send(() => addon().renderChain(ch, sr, settings, mode, onProgress || undefined));
+    return { audioBuffer: makeAB(r.channels, sr), lufs: r.lufs, measuredLufs: r.measuredLufs };
+  }
+  terminate() {                                                                      // :282
+    if (this.worker) {
+      this.worker = null; this.isReady = false;
+      for (const [, p] of this.pending) p.reject(new Error('Worker terminated'));
+      this.pending.clear();
+    }
+  }
+}
+let sharedInstance = null;
+export function getDSPWorker() { if (!sharedInstance) sharedInstance = new DSPWorkerInterface(); return sharedInstance; }
+export async function initDSPWorker() { const w = getDSPWorker(); await w.init(); return w; }

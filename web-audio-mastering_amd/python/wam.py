@@ -225,6 +225,11 @@ def apply_multiband_transient(chans, sr):
     return _stage(lib().wam_multiband_transient, chans, C.c_double(sr))
 
 
+def apply_gain(chans, gain_db):
+    """applyGain(audioBuffer, gainDB) - web/lib/dsp/normalizer.js:103"""
+    return _stage(lib().wam_apply_gain, chans, C.c_double(gain_db))
+
+
 def normalize(chans, sr, target_lufs=-14.0, ceiling_db=-1.0):
     """DSPWorkerInterface.normalize - worker-interface.js:197"""
     pin, keep = _ptrs(chans)
