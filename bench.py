@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402  (first: libwam_hip.so must bind to the same HIP runtime as torch)
 import torch.distributed as dist  # noqa: E402
 import wam  # noqa: E402
+import wam_dist  # noqa: E402
 
 SR = 48000
 SECONDS = 180
@@ -133,9 +134,7 @@ def main():
         return wam.batch_meter_dev(x.data_ptr(), T, NCH, N, SR)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        wam_dist.barrier(dev)
 
     for _ in range(args.warmup):
         step()
@@ -149,10 +148,13 @@ def main():
     dt = time.perf_counter() - t0
     prof = profile_read()
     wam.lib().wam_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = wam_dist.max_over_ranks(dt, dev)
+    # per-track scalars of every shard, in global track order (the only data that leaves a rank)
+    if args.workload == "chain":
+        local = [[r.lufs, r.true_peak_db, r.lufs_in, r.gain_db] for r in res]
+    else:
+        local = [[float(a), float(b)] for a, b in zip(res[0], res[1])]
+    table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64), world * T, dev)
 
     if rank == 0:
         audio_s = world * T * SECONDS * args.steps
@@ -194,10 +196,11 @@ def main():
             "kernel_ms_per_step": kernel_ms_per_step,
             "kernels": kernels,
         }
+        tb = table.cpu()
+        out["sample_result"] = {"lufs": float(tb[0, 0]), "true_peak_db": float(tb[0, 1]), "tracks_reported": int(tb.shape[0]),
+                                "lufs_min": float(tb[:, 0].min()), "lufs_max": float(tb[:, 0].max()), "true_peak_db_max": float(tb[:, 1].max())}
         if args.workload == "chain":
-            out["sample_result"] = {"lufs": res[0].lufs, "true_peak_db": res[0].true_peak_db, "lufs_in": res[0].lufs_in, "gain_db": res[0].gain_db}
-        else:
-            out["sample_result"] = {"lufs": float(res[0][0]), "true_peak_db": float(res[1][0])}
+            out["sample_result"].update(lufs_in=float(tb[0, 2]), gain_db=float(tb[0, 3]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
