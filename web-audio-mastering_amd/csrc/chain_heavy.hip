@@ -19,17 +19,17 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
                                                       const HeavyPlan* __restrict__ hp, double pre_gain) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[1][kCtxFloats];
-  const HeavyPlan& P = *hp;
   const int64_t chan = blockIdx.x;
   const float* x = in + chan * n;
   float* y = out + chan * n;
   LdsSlots slots(lds_scan);
   double P1[4];
-  biquad_lane_power(P.exc_hp, lane_id(), P1);
+  biquad_lane_power(hp->exc_hp, lane_id(), P1);
   double Sa[2] = {0, 0}, Sb[2] = {0, 0};
   const double mix = 0.15 / 100, drive = 0.5, bias = 0.2;     // constants.js:36-42, exciter.js:88
   const int64_t ntiles = (n + kTile - 1) / kTile;
   for (int64_t t = 0; t < ntiles; t++) {
+    const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     float v[C];
     load_chunk(x, n, base, v);
@@ -67,9 +67,9 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     float o[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      const double wetA = tanh(f[k + 1] * drive + bias);
+      const double wetA = tanh_fast(f[k + 1] * drive + bias);
       const double sB = catmull_half(f[k], f[k + 1], f[k + 2], f[k + 3]);
-      const double wetB = tanh(sB * drive + bias);
+      const double wetB = tanh_fast(sB * drive + bias);
       const double wet = (wetA + wetB) * 0.5;
       o[k] = f32r((double)v[k] + wet * mix);
     }
@@ -131,9 +131,13 @@ __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, co
 #pragma unroll
   for (int i = 0; i < 8; i++) { st.S[i][0] = 0; st.S[i][1] = 0; }
 }
+// Bands are handed to `consume(band_index, float band[C])` one at a time (low, mid, high) so that only one band
+// is live in registers while it is processed.
+template <class Consume>
 __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float xm2, SplitState& st, const Biquad& lp1, const Biquad& hp1,
-                                            const Biquad& lp2, const Biquad& hp2, LdsSlots& slots, float lo[C], float mid[C], float hi[C]) {
+                                            const Biquad& lp2, const Biquad& hp2, LdsSlots& slots, Consume consume) {
   double d[C], s0, s1, t0, t1;
+  float band[C];
   // low = lp1(lp1(x))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = v[k];
@@ -142,7 +146,8 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
   biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), lp1, st.P[0], st.S[1][0], st.S[1][1], slots.next(), t0, t1);
 #pragma unroll
-  for (int k = 0; k < C; k++) lo[k] = f32r(d[k]);
+  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
+  consume(0, band);
   // midHigh = hp1(hp1(x))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = v[k];
@@ -162,7 +167,8 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
   biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), lp2, st.P[2], st.S[5][0], st.S[5][1], slots.next(), t0, t1);
 #pragma unroll
-  for (int k = 0; k < C; k++) mid[k] = f32r(d[k]);
+  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
+  consume(1, band);
   // high = hp2(hp2(mh))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = mh[k];
@@ -171,28 +177,37 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
   biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), hp2, st.P[3], st.S[7][0], st.S[7][1], slots.next(), t0, t1);
 #pragma unroll
-  for (int k = 0; k < C; k++) hi[k] = f32r(d[k]);
+  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
+  consume(2, band);
 }
 
-__global__ __launch_bounds__(kThreads) void k_warm_punch(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
-                                                         const HeavyPlan* __restrict__ hp, int do_warm, int do_punch,
+// WARM / PUNCH are compile-time so that each instantiation carries only its own filter state: the two stages run as
+// two launches (the second in place on the first's output: a tile is fully read before it is written), which costs
+// 8 B per sample-channel of extra traffic on a kernel that is bound by f64 issue, not by HBM.
+template <bool do_warm, bool do_punch>
+__global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float* out, int nch, int64_t n,
+                                                         const HeavyPlan* __restrict__ hp,
                                                          const float* __restrict__ env, double pre_gain) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[2][kCtxFloats];
-  const HeavyPlan& P = *hp;
   const int64_t chan = blockIdx.x;
   const int64_t trk = chan / nch;
   const float* x = in + chan * n;
   float* y = out + chan * n;
-  const float* ev = env ? env + trk * P.w_nw : nullptr;
+  const float* ev = env ? env + trk * hp->w_nw : nullptr;
   LdsSlots slots(lds_scan);
   SplitState sw, sp;
-  if (do_warm) split_init(sw, P.w_lp1, P.w_hp1, P.w_lp2, P.w_hp2);
-  if (do_punch) split_init(sp, P.p_lp1, P.p_hp1, P.p_lp2, P.p_hp2);
+  if (do_warm) split_init(sw, hp->w_lp1, hp->w_hp1, hp->w_lp2, hp->w_hp2);
+  if (do_punch) split_init(sp, hp->p_lp1, hp->p_hp1, hp->p_lp2, hp->p_hp2);
   double Sf[3] = {0, 0, 0}, Ss[3] = {0, 0, 0}, Sg[3] = {1, 1, 1};
-  const double Psm = onepole_lane_power(P.p_smooth, lane_id());
+  const double Psm = onepole_lane_power(hp->p_smooth, lane_id());
+  // bypass-envelope window of this thread's chunk start, advanced tile by tile without divisions
+  const int64_t ws = hp->w_ws > 0 ? hp->w_ws : 1;
+  int64_t win = ((int64_t)threadIdx.x * C) / ws, wpos = ((int64_t)threadIdx.x * C) % ws;
+  const int64_t tile_q = kTile / ws, tile_r = kTile % ws;
   const int64_t ntiles = (n + kTile - 1) / kTile;
   for (int64_t t = 0; t < ntiles; t++) {
+    const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
     float v[C];
@@ -205,59 +220,71 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* __restrict
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
       prev_ctx<2>(last, pv, ctx[0], par, t == 0);
-      float band[3][C];
-      split_chunk(v, pv[1], pv[0], sw, P.w_lp1, P.w_hp1, P.w_lp2, P.w_hp2, slots, band[0], band[1], band[2]);
+      // envelope[min(floor(i / windowSamples), numWindows - 1)] (multiband-saturation.js:335-337); windowSamples >= C
+      // (checked by enqueue_warm_env), so a chunk crosses at most one window boundary
+      const int64_t nwl = P.w_nw - 1;
+      const double e_here = (double)ev[win < nwl ? win : nwl], e_next = (double)ev[win + 1 < nwl ? win + 1 : nwl];
+      const int64_t to_next = ws - wpos;
+      double acc[C];
+      auto saturate = [&](int b, const float band[C]) {
+        // saturateBand, multiband-saturation.js:292-308 (gain 0 dB); the three bands are summed left to right (:345)
+        const double drive = P.w_drive[b], bias = P.w_bias[b], bo = P.w_bo[b], mk = P.w_mk[b], mix = P.w_mix[b];
 #pragma unroll
-      for (int k = 0; k < C; k++) {
-        int64_t wi = (base + k) / P.w_ws; if (wi > P.w_nw - 1) wi = P.w_nw - 1;
-        const double e = (base + k < n) ? (double)ev[wi] : 0.0;
-        float sat[3];
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-          // saturateBand, multiband-saturation.js:292-308 (gain 0 dB)
-          const double dry = band[b][k];
-          const double wet = (tanh(P.w_drive[b] * (dry + P.w_bias[b])) - P.w_bo[b]) * P.w_mk[b];
-          const double sa = e * P.w_mix[b];
-          sat[b] = f32r((dry * (1 - sa) + wet * sa) * 1.0);
+        for (int k = 0; k < C; k++) {
+          if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // keep a few tanh evaluations in flight, not sixteen
+          double e = (k < to_next) ? e_here : e_next;
+          if (base + k >= n) e = 0.0;
+          const double dry = band[k];
+          const double wet = (tanh_fast(drive * (dry + bias)) - bo) * mk;
+          const double sa = e * mix;
+          const double sat = (double)f32r((dry * (1 - sa) + wet * sa) * 1.0);
+          acc[k] = (b == 0) ? sat : acc[k] + sat;
         }
-        v[k] = f32r((double)sat[0] + (double)sat[1] + (double)sat[2]);
-      }
+      };
+      split_chunk(v, pv[1], pv[0], sw, P.w_lp1, P.w_hp1, P.w_lp2, P.w_hp2, slots, saturate);
+#pragma unroll
+      for (int k = 0; k < C; k++) v[k] = f32r(acc[k]);
     }
     if (do_punch) {
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
       prev_ctx<2>(last, pv, ctx[1], par, t == 0);
-      float band[3][C];
-      split_chunk(v, pv[1], pv[0], sp, P.p_lp1, P.p_hp1, P.p_lp2, P.p_hp2, slots, band[0], band[1], band[2]);
-      float res[3][C];
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
+      double acc[C];
+      auto transient = [&](int b, const float band[C]) {
         // processTransients, multiband-transient.js:194-263
+        const double fA = P.pf_A[b], fR = P.pf_R[b], sA = P.ps_A[b], sR = P.ps_R[b], tg = P.p_tg[b] - 1, sg = P.p_sg[b] - 1;
+        const double osm = 1 - P.p_smooth.c;
         double a[C];
 #pragma unroll
-        for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabs((double)band[b][k]) : 0.0;
-        double fe = follower_solve(a, P.pf_A[b], P.pf_R[b], Sf[b], slots.next());
-        double se = follower_solve(a, P.ps_A[b], P.ps_R[b], Ss[b], slots.next());
+        for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabs((double)band[k]) : 0.0;
+        double fe = follower_solve(a, fA, fR, Sf[b], slots.next());
+        double se = follower_solve(a, sA, sR, Ss[b], slots.next());
         double u[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-          fe = follower_step(fe, a[k], P.pf_A[b], P.pf_R[b]);
-          se = follower_step(se, a[k], P.ps_A[b], P.ps_R[b]);
+          fe = follower_step(fe, a[k], fA, fR);
+          se = follower_step(se, a[k], sA, sR);
           const double diff = fe - se;
-          double target;
-          if (diff > 0) { const double st = se > 0.0001 ? fmin(diff / se, 1.0) : fmin(diff / 0.0001, 1.0); target = 1 + (P.p_tg[b] - 1) * st; }
-          else { const double st = se > 0.0001 ? fmin(-diff / se, 1.0) : fmin(-diff / 0.0001, 1.0); target = 1 + (P.p_sg[b] - 1) * st; }
-          u[k] = (1 - P.p_smooth.c) * target;
+          // strength = min(|diff| / max-guard(slowEnv, 1e-4), 1); gain towards the transient or the sustain target
+          const double st = fmin(fabs(diff) / (se > 0.0001 ? se : 0.0001), 1.0);
+          const double target = 1 + (diff > 0 ? tg : sg) * st;
+          u[k] = osm * target;
         }
         double s;
         onepole_chunk(u, P.p_smooth, Psm, Sg[b], slots.next(), s);
 #pragma unroll
-        for (int k = 0; k < C; k++) res[b][k] = f32r((double)band[b][k] * u[k]);
-      }
+        for (int k = 0; k < C; k++) {
+          const double r = (double)f32r((double)band[k] * u[k]);
+          acc[k] = (b == 0) ? r : acc[k] + r;
+        }
+      };
+      split_chunk(v, pv[1], pv[0], sp, P.p_lp1, P.p_hp1, P.p_lp2, P.p_hp2, slots, transient);
 #pragma unroll
-      for (int k = 0; k < C; k++) v[k] = f32r((double)res[0][k] + (double)res[1][k] + (double)res[2][k]);
+      for (int k = 0; k < C; k++) v[k] = f32r(acc[k]);
     }
     store_chunk(y, n, base, v);
+    win += tile_q; wpos += tile_r;
+    if (wpos >= ws) { wpos -= ws; win++; }
   }
 }
 
@@ -272,6 +299,7 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
                      double pre_gain, hipStream_t s) {
   if (n <= 0) return WAM_OK;
   const int64_t nw = hp_host.w_nw, ws = hp_host.w_ws;
+  if (ws < C) { set_error("tape warmth needs a bypass window of at least %d samples (sample rate too low)", C); return WAM_ERR_INVALID; }
   WAM_HIP(hipMemsetAsync(winpeak, 0, sizeof(unsigned) * (size_t)nw * ntracks, s));
   int64_t bx = nw < 512 ? nw : 512;
   WAM_LAUNCH("k_win_peak", k_win_peak, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, nch, n, ws, nw, winpeak, pre_gain);
@@ -284,7 +312,11 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
                        const float* env, double pre_gain, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  WAM_LAUNCH("k_warm_punch", k_warm_punch, dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, do_warm, do_punch, env, pre_gain);
+  if (do_warm) WAM_LAUNCH("k_warm", (k_warm_punch<true, false>), dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain);
+  if (do_punch) {
+    const float* src = do_warm ? out : in;
+    WAM_LAUNCH("k_punch", (k_warm_punch<false, true>), dim3(ntracks * nch), dim3(kThreads), s, src, out, nch, n, plan_dev, env, do_warm ? 1.0 : pre_gain);
+  }
   return WAM_OK;
 }
 

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ i
           // soft-clipper.js:200-207
           const double excess = a - P.thr_lin;
           const double normalized = excess / P.range_div;
-          const double sat = tanh(normalized * P.drive);
+          const double sat = tanh_fast(normalized * P.drive);
           const double target = P.thr_lin + sat * P.range;
           r[k] = fmin(r[k], target / a);
           any = true;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__
         const double a = fabs(v2[q]);
         if (a > ceil_lin) {
           const double ex = (a - ceil_lin) / ceil_lin;
-          const double red = 1 - tanh(ex * 2) * 0.1;
+          const double red = 1 - tanh_fast(ex * 2) * 0.1;
           const double m = fmin(a * red, ceil_lin);
           v2[q] = v2[q] > 0 ? m : -m;
         }
@@ -379,7 +379,7 @@ __device__ __forceinline__ double soft_knee_curve(double s, double ceiling, doub
     o = a + (ceiling - a) * blend * 0.5;
   } else {
     const double nrm = (a - ceiling) / ceiling;
-    const double comp = 1 - tanh(nrm * 2) * 0.1;
+    const double comp = 1 - tanh_fast(nrm * 2) * 0.1;
     o = fmin(ceiling, a * comp);
   }
   return s > 0 ? o : -o;

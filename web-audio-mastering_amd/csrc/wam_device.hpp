@@ -29,12 +29,10 @@ constexpr int kTile = kThreads * C;    // 4096 samples
 // ---- host-prepared plans ---------------------------------------------------
 struct Biquad {            // y[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2] - a1 y[n-1] - a2 y[n-2]
   double b0, b1, b2, a1, a2;
-  double h1[C], h2[C];     // response at n to unit start state (y[-1], y[-2]) = (1,0) / (0,1)
   double Mp[7][4];         // M^(2^k), k = 0..6, M = transition of the state over one chunk (C samples)
 };
 struct OnePole {           // y[n] = c y[n-1] + u[n]
   double c;
-  double cp[C];            // c^(n+1)
   double Mp[7];            // (c^C)^(2^k)
 };
 
@@ -42,6 +40,46 @@ struct OnePole {           // y[n] = c y[n-1] + u[n]
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ float f32r(double v) { return (float)v; }   // the Float32Array store
+
+// Make a plan pointer opaque once per tile: the compiler then reloads plan constants through the
+// scalar cache where they are used instead of hoisting hundreds of them out of the tile loop and
+// spilling them to VGPR lanes (v_writelane/v_readlane cost VALU issue slots; s_load does not).
+template <class T>
+__device__ __forceinline__ const T* reload_each_tile(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// tanh in double, |error| < 2e-15 absolute (the callers add the result to a signal that is then
+// rounded to f32).  tanh|x| = (1 - t) / (1 + t), t = exp(-2|x|): range reduction by ln 2,
+// degree-12 Taylor polynomial on |r| <= ln2/2, reciprocal by v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double tanh_fast(double x) {
+  const double ax = fabs(x);
+  const double z = -2.0 * fmin(ax, 20.0);                 // t < 5e-18 beyond: tanh rounds to 1
+  const double k = rint(z * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, z);      // ln2 hi / lo
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;                  // 1/12!
+  p = fma(p, r, 2.50521083854417187751e-08);
+  p = fma(p, r, 2.75573192239858906526e-07);
+  p = fma(p, r, 2.75573192239858906526e-06);
+  p = fma(p, r, 2.48015873015873015873e-05);
+  p = fma(p, r, 1.98412698412698412698e-04);
+  p = fma(p, r, 1.38888888888888888889e-03);
+  p = fma(p, r, 8.33333333333333333333e-03);
+  p = fma(p, r, 4.16666666666666666667e-02);
+  p = fma(p, r, 1.66666666666666666667e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double t = ldexp(p, (int)k);
+  const double d = 1.0 + t;
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  const double m = (1.0 - t) * y;
+  return copysign(m, x);
+}
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -109,20 +147,31 @@ __device__ __forceinline__ void scan2(double& e0, double& e1, const Biquad& q, c
 // xm1/xm2 = the two inputs before the chunk.  s0/s1 returns the chunk's start
 // state (y[-1], y[-2]) = the previous thread's last two outputs in double: the
 // next cascaded stage takes its xm1/xm2 from them (after the f32 store rounding).
+// Three phases: feed-forward part in place; the recursion from zero state for the
+// chunk's end state only; scan; the recursion again from the true start state, which
+// reproduces the sequential DF-I evaluation order of utils.js:12-25 given that state.
 __device__ __forceinline__ void biquad_chunk(double x[C], double xm1, double xm2, const Biquad& q, const double P[4],
                                              double& S0, double& S1, double* lds, double& s0, double& s1) {
+  const double b0 = q.b0, b1 = q.b1, b2 = q.b2, a1 = q.a1, a2 = q.a2;
   double p1 = 0, p2 = 0, i1 = xm1, i2 = xm2;
 #pragma unroll
   for (int n = 0; n < C; n++) {
     const double xi = x[n];
-    const double y = q.b0 * xi + q.b1 * i1 + q.b2 * i2 - q.a1 * p1 - q.a2 * p2;
-    i2 = i1; i1 = xi; p2 = p1; p1 = y;
-    x[n] = y;
+    const double w = b0 * xi + b1 * i1 + b2 * i2;
+    i2 = i1; i1 = xi;
+    x[n] = w;
+    const double y = w - a1 * p1 - a2 * p2;
+    p2 = p1; p1 = y;
   }
   s0 = p1; s1 = p2;
   scan2(s0, s1, q, P, S0, S1, lds);
+  p1 = s0; p2 = s1;
 #pragma unroll
-  for (int n = 0; n < C; n++) x[n] += q.h1[n] * s0 + q.h2[n] * s1;
+  for (int n = 0; n < C; n++) {
+    const double y = x[n] - a1 * p1 - a2 * p2;
+    p2 = p1; p1 = y;
+    x[n] = y;
+  }
 }
 
 // ---- first-order scan ----------------------------------------------------------
@@ -149,13 +198,15 @@ __device__ __forceinline__ void scan1(double& e, const OnePole& q, double Pl, do
 }
 // y[n] = c y[n-1] + u[n] over the chunk, in place on u[]; returns start state in s.
 __device__ __forceinline__ void onepole_chunk(double u[C], const OnePole& q, double Pl, double& S, double* lds, double& s) {
+  const double c = q.c;
   double p = 0;
 #pragma unroll
-  for (int n = 0; n < C; n++) { p = q.c * p + u[n]; u[n] = p; }
+  for (int n = 0; n < C; n++) p = c * p + u[n];
   s = p;
   scan1(s, q, Pl, S, lds);
+  p = s;
 #pragma unroll
-  for (int n = 0; n < C; n++) u[n] += q.cp[n] * s;
+  for (int n = 0; n < C; n++) { p = c * p + u[n]; u[n] = p; }
 }
 
 // ---- affine scan (per-thread coefficients), used by the follower policy iteration ----
@@ -196,18 +247,19 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
 template <class Run>
 __device__ __forceinline__ double solve_piecewise(Run run, double guess, double& S, double* lds, int max_iter = 260) {
   const double S_in = S;
-  unsigned prev_mask = 0xFFFFFFFFu;
   double start = guess;
   for (int it = 0; it < max_iter; it++) {
-    double al, be; unsigned mask;
-    run(start, al, be, mask);
+    double al, be;
+    run(start, al, be);
     double Sc = S_in;
     const double ns = scan_affine(al, be, Sc, lds);
-    const int changed = __syncthreads_or((mask != prev_mask) || (it == 0));   // also fences the reuse of lds
+    // Fixed point: the maps composed under this iteration's branches reproduce the start values they
+    // were run from, so branches, maps and start values are mutually consistent.  (Comparing bit
+    // patterns: identical maps scan to identical values.)
+    const int changed = __syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(start));   // also fences the reuse of lds
     S = Sc;
-    if (!changed) break;
-    prev_mask = mask;
     start = ns;
+    if (!changed) break;
   }
   return start;
 }
@@ -216,17 +268,16 @@ __device__ __forceinline__ double solve_piecewise(Run run, double guess, double&
 // multiband-transient.js:219-230): e' = (a > e) ? A e + (1-A) a : R e + (1-R) a.
 // a[] = rectified input of the chunk.  Returns the chunk's true start value.
 __device__ __forceinline__ double follower_solve(const double a[C], double A, double R, double& S, double* lds) {
-  const double oA = 1 - A, oR = 1 - R;
-  auto run = [&](double e, double& al, double& be, unsigned& mask) {
-    al = 1; be = 0; mask = 0;
+  // (al, be) are functions of the branch pattern only (never of e0's low bits), so the fixed-point test of
+  // solve_piecewise terminates as soon as the pattern is stable.  The envelope itself is materialised by follower_step.
+  auto run = [&](double e0, double& al, double& be) {
+    al = 1; be = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
-      const bool att = a[n] > e;
-      const double c = att ? A : R, oc = att ? oA : oR;
-      e = c * e + oc * a[n];
-      be = c * be + oc * a[n];
+      const double e = fma(al, e0, be);
+      const double c = (a[n] > e) ? A : R;
+      be = fma(c, be - a[n], a[n]);          // = c be + (1 - c) a
       al = c * al;
-      mask |= (att ? 1u : 0u) << n;
     }
   };
   return solve_piecewise(run, S, S, lds);
@@ -241,15 +292,15 @@ __device__ __forceinline__ double follower_step(double e, double a, double A, do
 // g[] = this chunk's raw gains (f32 values).  rcC = rc^C.  Returns the chunk's start value.
 __device__ __forceinline__ double release_solve(const float g[C], double rc, double rcC, double& S, double* lds) {
   const double orc = 1 - rc;
-  auto run = [&](double cur, double& al, double& be, unsigned& mask) {
-    mask = 0;
+  auto run = [&](double cur, double& al, double& be) {
+    bool reset = false;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double gn = (double)g[n];
-      if (gn < cur) { cur = gn; mask |= 1u << n; }
+      if (gn < cur) { cur = gn; reset = true; }
       else { cur = rc * cur + orc * 1.0; cur = fmin(cur, 1.0); }
     }
-    if (mask) { al = 0; be = cur; } else { al = rcC; be = 1 - rcC; }
+    if (reset) { al = 0; be = cur; } else { al = rcC; be = 1 - rcC; }
   };
   // first guess: pure release from the carry (exact when the tile has no reset)
   double guess = S;

@@ -16,13 +16,14 @@ inline void mat2_mul_h(const double a[4], const double b[4], double o[4]) {
 // Fill the scan tables of a biquad from its five coefficients.
 inline void finish_biquad(Biquad& q) {
   // homogeneous responses
+  double h1[C], h2[C];
   double p1 = 1, p2 = 0;
-  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; q.h1[n] = y; p2 = p1; p1 = y; }
+  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; h1[n] = y; p2 = p1; p1 = y; }
   p1 = 0; p2 = 1;
-  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; q.h2[n] = y; p2 = p1; p1 = y; }
+  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; h2[n] = y; p2 = p1; p1 = y; }
   // state after C samples: (y[C-1], y[C-2]) = M (y[-1], y[-2])
-  q.Mp[0][0] = q.h1[C - 1]; q.Mp[0][1] = q.h2[C - 1];
-  q.Mp[0][2] = q.h1[C - 2]; q.Mp[0][3] = q.h2[C - 2];
+  q.Mp[0][0] = h1[C - 1]; q.Mp[0][1] = h2[C - 1];
+  q.Mp[0][2] = h1[C - 2]; q.Mp[0][3] = h2[C - 2];
   for (int k = 1; k < 7; k++) mat2_mul_h(q.Mp[k - 1], q.Mp[k - 1], q.Mp[k]);
 }
 inline Biquad make_biquad(double b0, double b1, double b2, double a1, double a2) {
@@ -96,9 +97,9 @@ inline Biquad webaudio_biquad(int type /*0 lowshelf, 1 peaking, 2 highshelf*/, d
 
 inline OnePole make_onepole(double c) {
   OnePole q; q.c = c;
-  double p = c;
-  for (int n = 0; n < C; n++) { q.cp[n] = p; p *= c; }
-  q.Mp[0] = q.cp[C - 1];
+  double p = 1;
+  for (int n = 0; n < C; n++) p *= c;
+  q.Mp[0] = p;
   for (int k = 1; k < 7; k++) q.Mp[k] = q.Mp[k - 1] * q.Mp[k - 1];
   return q;
 }
