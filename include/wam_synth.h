@@ -31,6 +31,11 @@ int wam_synth_dev(float* out_dev, int ntracks, int nch, int64_t n, double sample
 int wam_profile_enable(int on);
 int wam_profile_read(char* buf, size_t cap);
 
+/* Time-segmentation knobs ("Segments"): "dh_seg_frames", "dh_warm_frames", "env_seg_tiles",
+ * "sc_warm_tiles", "lim_warm_tiles"; "reset" restores the defaults.  Process-wide; meant for tests that make short
+ * fixtures cross segment seams, and for tuning runs. */
+int wam_tune(const char* key, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif

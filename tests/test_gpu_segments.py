@@ -1,0 +1,90 @@
+"""Time segmentation: kernels that split a track into segments and rebuild their state by re-running a warm-up
+stretch must give the same samples as one sequential walk.  The knobs are shrunk (wam.tune) so that short inputs
+cross many segment seams; every case is compared with the sequential CPU oracle, to the PCM bar of 1e-5, and with
+the unsegmented GPU result, which it should match far more closely.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+wam = pytest.importorskip("wam")
+
+TOL = 1e-5
+SEAM_TOL = 2e-7      # segmented vs unsegmented GPU: warm-up residue + f32 store flips
+
+
+def maxerr(a, b):
+    a = np.stack([np.asarray(x, dtype=np.float64) for x in a])
+    b = np.stack([np.asarray(x, dtype=np.float64) for x in b])
+    return float(np.max(np.abs(a - b)))
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    yield
+    wam.tune("reset")
+
+
+@pytest.fixture(scope="module")
+def hot():
+    sr = 48000
+    return sr, O.synth(11, 2, 3 * sr + 777, sr, {"amp": 2.4, "clickAmp": 0.8, "dc": 0.002})
+
+
+def test_deharsh_segments(hot):
+    sr, x = hot
+    ref = O.deharsh(x, sr)
+    wam.tune("dh_seg_frames", 1 << 20)
+    whole = wam.process_hybrid_dynamic(x, sr)
+    assert maxerr(whole, ref) <= TOL
+    for seg, warm in ((16, 48), (7, 40), (64, 48)):
+        wam.tune("dh_seg_frames", seg)
+        wam.tune("dh_warm_frames", warm)
+        y = wam.process_hybrid_dynamic(x, sr)
+        assert maxerr(y, ref) <= TOL
+        assert maxerr(y, whole) <= SEAM_TOL
+
+
+def test_soft_clip_segments(hot):
+    sr, x = hot
+    ref = O.soft_clip(x, sr, -1.0, 0.5, 10.0, 1.5)
+    wam.tune("env_seg_tiles", 1 << 20)
+    whole = wam.apply_mastering_soft_clip(x, sr, ceiling=-1.0)
+    assert maxerr(whole, ref) <= TOL
+    for seg, warm in ((1, 3), (2, 4), (5, 3)):
+        wam.tune("env_seg_tiles", seg)
+        wam.tune("sc_warm_tiles", warm)
+        y = wam.apply_mastering_soft_clip(x, sr, ceiling=-1.0)
+        assert maxerr(y, ref) <= TOL
+        assert maxerr(y, whole) <= SEAM_TOL
+
+
+@pytest.mark.parametrize("preserve", [True, False])
+def test_limiter_segments(hot, preserve):
+    sr, x = hot
+    ceil = 10 ** (-1 / 20)
+    ref = O.limiter(x, sr, ceil, preserve=preserve)
+    wam.tune("env_seg_tiles", 1 << 20)
+    whole = wam.apply_lookahead_limiter(x, sr, ceil, preserve_transients=preserve)
+    assert maxerr(whole, ref) <= TOL
+    for seg, warm in ((1, 25), (3, 25), (2, 30)):
+        wam.tune("env_seg_tiles", seg)
+        wam.tune("lim_warm_tiles", warm)
+        y = wam.apply_lookahead_limiter(x, sr, ceil, preserve_transients=preserve)
+        assert maxerr(y, ref) <= TOL
+        assert maxerr(y, whole) <= SEAM_TOL
+
+
+def test_chain_segments_long():
+    """A 25 s track through the whole chain with small segments everywhere, against the sequential oracle."""
+    sr = 48000
+    x = O.synth(5, 2, 25 * sr + 123, sr, {"amp": 1.8, "clickAmp": 0.7})
+    s = dict(wam.DEFAULT_SETTINGS, glueCompression=True)
+    ref, rres = O.render_chain(x, sr, s, "export")
+    wam.tune("env_seg_tiles", 16)
+    wam.tune("dh_seg_frames", 128)
+    y, res = wam.render_full_chain(x, sr, s, "export")
+    assert maxerr(y, ref) <= TOL
+    assert abs(res.lufs - rres.lufs) <= 0.01

@@ -22,6 +22,8 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 
+Tuning& tuning() { static Tuning t; return t; }
+
 // ---- per-kernel timing ------------------------------------------------------
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 static bool g_prof_on = false;
@@ -101,6 +103,19 @@ extern "C" {
 const char* wam_last_error(void) { return g_err.c_str(); }
 const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
 
+int wam_tune(const char* key, int64_t value) {
+  if (!key || value < 0) { wam::set_error("wam_tune: bad argument"); return WAM_ERR_INVALID; }
+  wam::Tuning& t = wam::tuning();
+  const std::string k = key;
+  if (k == "dh_seg_frames" && value >= 4) t.dh_seg_frames = value;
+  else if (k == "dh_warm_frames" && value >= 3) t.dh_warm_frames = value;
+  else if (k == "env_seg_tiles" && value >= 1) t.env_seg_tiles = value;
+  else if (k == "sc_warm_tiles" && value >= 1) t.sc_warm_tiles = value;
+  else if (k == "lim_warm_tiles" && value >= 1) t.lim_warm_tiles = value;
+  else if (k == "reset") t = wam::Tuning();
+  else { wam::set_error("wam_tune: unknown key or value out of range: %s = %lld", key, (long long)value); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
 int wam_profile_enable(int on) { g_prof_on = on != 0; return WAM_OK; }
 
 int wam_profile_read(char* buf, size_t cap) {

@@ -38,9 +38,9 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s);
 
-int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev,
+int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
                       const double* gains_dev, hipStream_t s);
-int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev,
+int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s);
 
 int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, hipStream_t s);

@@ -295,12 +295,12 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     if (do_limit) {
       rc = prog(0.85, "Applying soft clipper..."); if (rc) return rc;
       float* dst = next_dst();
-      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, have_gain ? gains_d : nullptr, stream); if (rc) return rc;
+      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, cp.L, have_gain ? gains_d : nullptr, stream); if (rc) return rc;
       src = dst;
       rc = prog(0.95, "Applying final limiter..."); if (rc) return rc;
       dst = next_dst();
       WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, stream));
-      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, stream); if (rc) return rc;
+      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, lp.L, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, stream); if (rc) return rc;
       src = dst;
       rc = enqueue_gate(mp, T, M2, stream); if (rc) return rc;
       final_meter = &M2;
@@ -379,7 +379,7 @@ int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double 
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan, genv; rc = upload_plan(cp, plan, nullptr); if (rc) return rc;
   rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
-  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), nullptr, nullptr);
+  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), cp.L, nullptr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
@@ -394,7 +394,7 @@ int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ce
   DevBuf plan, genv, tm; rc = upload_plan(lp, plan, nullptr); if (rc) return rc;
   rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
   rc = tm.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
-  rc = enqueue_limiter(st.in.as<float>(), st.out.as<float>(), tm.as<float>(), genv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(),
+  rc = enqueue_limiter(st.in.as<float>(), st.out.as<float>(), tm.as<float>(), genv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L,
                        preserve_transients != 0, nullptr, nullptr, 0, nullptr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);

@@ -177,9 +177,15 @@ __global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPla
   }
 }
 
+// Synthesis.  grid = (segments, channels): a workgroup owns the frames [f0, f1) of its segment and emits the samples
+// [f0 * 512, f1 * 512) (the last segment also the tail).  Frame-to-frame state is the per-bin resonance EMA
+// (avg' = 0.3 mag + 0.7 avg) and the overlap-add ring; a segment rebuilds both by re-running `warm` frames before
+// f0: the EMA forgets its start value as 0.7^warm, and the ring needs the three frames before f0.  Warm-up frames
+// more than three before f0 skip the inverse transform.
 __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                   const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
-                                                  const float* __restrict__ wing, const float* __restrict__ band_gain_db, double pre_gain) {
+                                                  const float* __restrict__ wing, const float* __restrict__ band_gain_db, double pre_gain,
+                                                  int64_t seg_frames, int64_t warm) {
   __shared__ float2 z[kN];
   __shared__ float2 tw[kN / 2];
   __shared__ float win[kN];
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
   __shared__ float ola[kN];      // overlap-add ring
   __shared__ float bg[kBands];
   const DeharshPlan& P = *dp;
-  const int64_t chan = blockIdx.x;
+  const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
   const int t = threadIdx.x;
@@ -200,10 +206,15 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
     return v;
   };
   const int64_t F = P.nframes;
-  if (F > 0) for (int i = t; i < kN - kHop; i += 256) xin[i] = load_in(i);     // first 1536 samples; each frame adds 512
+  const int64_t f0 = (int64_t)blockIdx.x * seg_frames;
+  int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
+  const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
+  const bool last_seg = f1 >= F;
+  if (F > 0) for (int i = t; i < kN - kHop; i += 256) { const int64_t s = fs * kHop + i; xin[s & (kN - 1)] = load_in(s); }   // each frame adds 512
   float avg[4] = {0, 0, 0, 0};
-  for (int64_t f = 0; f < F; f++) {
+  for (int64_t f = fs; f < f1; f++) {
     const int64_t pos = f * kHop;
+    const bool synth = f + 3 >= f0;        // this frame's output reaches samples the segment emits
     __syncthreads();
     // newest 512 samples of this frame: [pos + 1536, pos + 2048)
     for (int i = t; i < kHop; i += 256) { const int64_t s = pos + (kN - kHop) + i; xin[s & (kN - 1)] = load_in(s); }
@@ -226,19 +237,22 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
       const float2 c = z[p];
       const float mag = sqrtf(c.x * c.x + c.y * c.y);
       float res = 0.0f;
-      if (f == 0) avg[r] = mag;
+      if (f == fs) avg[r] = mag;            // the detector's first frame (:203-207); a warm start for later segments
       else {
         avg[r] = f32r(0.3 * (double)mag + (1 - 0.3) * (double)avg[r]);
         const double av = avg[r];
         if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, ((double)mag / av - 1.5) / 2));
       }
-      double gdb = bg[P.band_of[k]];
-      if (res > 0) gdb += -3.0 * (double)res * 0.2;
-      const float g = exp2f((float)(gdb * 0.16609640474436813));      // 10^(gdb/20), stored as f32 by the reference
-      const float2 s = make_float2(c.x * g, c.y * g);
-      z[p] = s;
-      if (k > 0) z[brev11(kN - k)] = make_float2(s.x, -s.y);          // mirror, :471-476
+      if (synth) {
+        double gdb = bg[P.band_of[k]];
+        if (res > 0) gdb += -3.0 * (double)res * 0.2;
+        const float g = exp2f((float)(gdb * 0.16609640474436813));      // 10^(gdb/20), stored as f32 by the reference
+        const float2 s = make_float2(c.x * g, c.y * g);
+        z[p] = s;
+        if (k > 0) z[brev11(kN - k)] = make_float2(s.x, -s.y);          // mirror, :471-476
+      }
     }
+    if (!synth) continue;                   // uniform across the workgroup
     __syncthreads();
     fft_inv(z, tw);
     // synthesis window + overlap-add (fft.js:63-65, dynamic-processor.js:483-487)
@@ -254,12 +268,15 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
     for (int i = t; i < kHop; i += 256) {
       const int64_t s = pos + i;
       const int o = (int)(s & (kN - 1));
-      const float w = f32r((double)ola[o] / 4.0);
-      y[s] = f32r((double)xin[o] * dry + (double)w * wetm);
+      if (f >= f0) {
+        const float w = f32r((double)ola[o] / 4.0);
+        y[s] = f32r((double)xin[o] * dry + (double)w * wetm);
+      }
       ola[o] = 0.0f;
     }
   }
   __syncthreads();
+  if (!last_seg) return;
   // tail: samples after the last frame's first hop keep their partial overlap-add sums (or none)
   const int64_t done = F > 0 ? F * kHop : 0;
   const int64_t ring_end = F > 0 ? (F - 1) * kHop + kN : 0;           // samples below this are in the ring
@@ -318,8 +335,10 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)((nchan * kBands + 63) / 64)), dim3(64), s, (const float*)rms.as<float>(),
                plan.as<DeharshPlan>(), nchan, gdb.as<float>());
   }
-  WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
-             winb.as<float>(), (const float*)gdb.as<float>(), pre_gain);
+  const int64_t seg = tuning().dh_seg_frames, warm = tuning().dh_warm_frames;
+  const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
+  WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)nseg, (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
+             winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return
   return WAM_OK;
 }

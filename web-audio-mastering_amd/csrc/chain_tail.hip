@@ -29,29 +29,39 @@ __device__ __forceinline__ double block_excl_sum(double v, double& total, double
 }
 
 // ============================================================================ soft clipper
-// Envelope.  One workgroup per track.  g_out: [ntracks][n] float.
+// Envelope.  grid = (segments, tracks).  g_out: [ntracks][n] float.
+// A sample over the threshold (an "event") pulls the gain of the L samples before it down along a ramp
+// (soft-clipper.js:194-219): every event scatters its ramp into an LDS window of the gains of
+// [tile_base - L, tile_end) with ds_min on the float bit patterns (all values are positive, and
+// f32(min(old, new)) == min(old, f32(new))), so the cost follows the number of events, not L x samples.
+// The release pass (:222-231) is the only state that outlives the window: its memory is exp(-k/(10 ms)), so a
+// segment re-runs `warm` tiles before its first tile instead of waiting for its predecessor.
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ in, int64_t n, const ClipPlan* __restrict__ cp,
-                                                     const double* __restrict__ gains, float* __restrict__ g_out) {
+                                                     const double* __restrict__ gains, float* __restrict__ g_out,
+                                                     int64_t seg_tiles, int64_t warm) {
   constexpr int kMaxL = 256;
-  __shared__ double rr[kMaxL + kTile];           // required gain per sample of [tile_base - L, tile_end); 2.0 = no event
+  __shared__ unsigned gwin[kMaxL + kTile];       // gain bits of [tile_base - L, tile_end)
+  __shared__ double rt[kMaxL + 1];               // ramp position m / L  (soft-clipper.js:213-214 with i - start == L)
   __shared__ double lds_scan[kSlotDoubles];
   const ClipPlan& P = *cp;
   const int L = P.L;
-  const int64_t trk = blockIdx.x;
+  const int64_t trk = blockIdx.y;
   const double G = gains ? gains[trk] : 1.0;
   float* go = g_out + trk * n;
   LdsSlots slots(lds_scan);
   double Scur = 1.0;
-  for (int i = threadIdx.x; i < L; i += kThreads) rr[i] = 2.0;
+  const unsigned one = __float_as_uint(1.0f);
+  for (int i = threadIdx.x; i < L + kTile; i += kThreads) gwin[i] = one;
+  for (int i = threadIdx.x; i <= L; i += kThreads) rt[i] = (double)i / (double)(L > 1 ? L : 1);
   const int64_t ntiles = (n + L + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
+  int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
+  const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  __syncthreads();
+  for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
-    double r[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) r[k] = 2.0;
-    bool any = false;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float v[C];
@@ -65,63 +75,42 @@ __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ i
           const double normalized = excess / P.range_div;
           const double sat = tanh_fast(normalized * P.drive);
           const double target = P.thr_lin + sat * P.range;
-          r[k] = fmin(r[k], target / a);
-          any = true;
-        }
-      }
-    }
-    __syncthreads();      // previous tile's readers of rr are done
-#pragma unroll
-    for (int k = 0; k < C; k++) rr[L + threadIdx.x * C + k] = r[k];
-    const int any_blk = __syncthreads_or(any);
-    // the window also holds the previous tile's last L samples: remember whether those had events
-    __shared__ int prev_any;
-    if (t == 0 && threadIdx.x == 0) prev_any = 0;
-    __syncthreads();
-    const int active = any_blk | prev_any;
-    // finalised samples of this tile: k in [tile_base - L, tile_end - L)
-    float g[C];
-    const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
-#pragma unroll
-    for (int k = 0; k < C; k++) g[k] = 1.0f;
-    if (active) {
+          const double red1 = target / a - 1.0;
+          const int64_t i = base + k;
+          const int wp = threadIdx.x * C + k;            // window index of sample i - L
+          if (i >= L) {
 #pragma unroll 1
-      for (int k = 0; k < C; k++) {
-        const int64_t kk = kb + k;
-        if (kk < 0 || kk >= n) continue;
-        float gm = 1.0f;
-        const int wl = threadIdx.x * C + k;            // window index of kk
-        for (int d = 0; d <= L; d++) {
-          const double req = rr[wl + d];
-          if (req < 1.5) {
-            const int64_t i = kk + d;
-            const int64_t st = i - L > 0 ? i - L : 0;
-            const double tt = (double)(kk - st) / (double)(i - st > 1 ? i - st : 1);      // soft-clipper.js:213-214
-            gm = fminf(gm, f32r(1.0 + (req - 1.0) * tt));
+            for (int m = 0; m <= L; m++) atomicMin(&gwin[wp + m], __float_as_uint(f32r(1.0 + red1 * rt[m])));
+          } else {                                        // ramp clipped at the start of the track: start = 0
+            const double den = (double)(i > 1 ? i : 1);
+#pragma unroll 1
+            for (int64_t j = 0; j <= i; j++) atomicMin(&gwin[L + (int)(j - tile_base)], __float_as_uint(f32r(1.0 + red1 * ((double)j / den))));
           }
         }
-        g[k] = gm;
       }
     }
-    // release smoothing (soft-clipper.js:222-231) over the finalised samples, in time order across tiles
-    float gs[C];
+    __syncthreads();
+    // finalised samples of this tile: [tile_base - L, tile_end - L)
+    const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
+    float gs[C], g[C];
 #pragma unroll
-    for (int k = 0; k < C; k++) gs[k] = (kb + k >= 0 && kb + k < n) ? g[k] : 1.0f;
-    // samples before 0 (first tile) are skipped: treat them as "no step" by making them pure releases from 1.0 (cur stays 1)
+    for (int k = 0; k < C; k++) { const float gv = __uint_as_float(gwin[threadIdx.x * C + k]); gs[k] = (kb + k >= 0 && kb + k < n) ? gv : 1.0f; }
+    // release smoothing (soft-clipper.js:222-231) in time order across tiles; samples before 0 are pure releases from 1.0
     double cur = release_solve(gs, P.rc, P.rcC, Scur, slots.next());
 #pragma unroll
     for (int k = 0; k < C; k++) { cur = release_step(cur, (double)gs[k], P.rc); g[k] = f32r(cur); }
-    if (kb + C > 0) {
+    if (t >= T0 && kb + C > 0) {
       if (kb >= 0) store_chunk(go, n, kb, g);
       else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
     }
     __syncthreads();
-    // slide the window
-    double keep = 2.0;
-    if (threadIdx.x < L) keep = rr[kTile + threadIdx.x];
+    // slide the window by one tile
+    unsigned keep = one;
+    if (threadIdx.x < L) keep = gwin[kTile + threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < L) rr[threadIdx.x] = keep;
-    if (threadIdx.x == 0) prev_any = any_blk;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = one;
+    if (threadIdx.x < L) gwin[threadIdx.x] = keep;
+    __syncthreads();
   }
 }
 
@@ -188,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__
 // Transient map (dsp-worker.js:306-362).  One workgroup per track.  tm: [ntracks][n] float.
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
-                                                     float* __restrict__ tm_out) {
+                                                     float* __restrict__ tm_out, int64_t seg_tiles, int64_t warm) {
   constexpr int kMaxW = 1024;
   __shared__ double pre[kTile + kTile / 16 + 8];       // padded inclusive prefix of the tile's mean squares
   __shared__ double tail[kMaxW + kMaxW / 16 + 8];      // previous tile's last W prefixes, relative to this tile's origin
@@ -196,14 +185,19 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   __shared__ double lds_sum[4];
   const LimiterPlan& P = *lp;
   const int W = P.W;
-  const int64_t trk = blockIdx.x;
+  const int64_t trk = blockIdx.y;
   float* tmo = tm_out + trk * n;
   LdsSlots slots(lds_scan);
   double Spk = 0;
   for (int i = threadIdx.x; i < kMaxW + kMaxW / 16 + 8; i += kThreads) tail[i] = 0;
   __syncthreads();
+  // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact after W <= 1024 samples
+  // and the peak follower forgets as exp(-k / (50 ms))
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
+  int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
+  const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     double q[C], pk[C];
@@ -244,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
       }
       tmv[k] = tmk;
     }
-    store_chunk(tmo, n, base, tmv);
+    if (t >= T0) store_chunk(tmo, n, base, tmv);
     __syncthreads();
     // next tile's tail = this tile's last W prefixes minus this tile's total
     double keep[4];
@@ -260,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
 // Lookahead gain (dsp-worker.js:367-425).  One workgroup per track.  g_out: [ntracks][n] float.
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
-                                                       const float* __restrict__ tm, float* __restrict__ g_out) {
+                                                       const float* __restrict__ tm, float* __restrict__ g_out, int64_t seg_tiles, int64_t warm) {
   constexpr int kMaxL = 1024;
   __shared__ float gwin_s[kMaxL + kTile];       // gain envelope of [tile_base - L, tile_end)
   __shared__ double lds_scan[kSlotDoubles];
@@ -268,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
   volatile float* gwin = gwin_s;
   const LimiterPlan& P = *lp;
   const int L = P.L;
-  const int64_t trk = blockIdx.x;
+  const int64_t trk = blockIdx.y;
   const float* tmi = tm ? tm + trk * n : nullptr;
   float* go = g_out + trk * n;
   LdsSlots slots(lds_scan);
@@ -276,8 +270,12 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
   for (int i = threadIdx.x; i < L + kTile; i += kThreads) gwin[i] = 1.0f;
   __syncthreads();
   const int lane = lane_id(), wave = wave_id();
+  // segment [T0, T1) of the tiles, entered `warm` tiles early (release memory exp(-k / (100 ms)); ramps reach back L)
   const int64_t ntiles = (n + L + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
+  int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
+  const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
@@ -290,7 +288,11 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
       float v[C], xp[3];
       load_chunk(in + (trk * NCH + c) * n, n, base, v);
       const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
-      prev_ctx<3>(last, xp, ctx[c], par, t == 0);
+      prev_ctx<3>(last, xp, ctx[c], par, t == Tw);
+      if (t == Tw && Tw > 0 && threadIdx.x == 0) {         // a later segment's first tile: the three samples before it come from memory
+        const float* xc = in + (trk * NCH + c) * n;
+        xp[0] = xc[base - 3]; xp[1] = xc[base - 2]; xp[2] = xc[base - 1];
+      }
       double y0 = xp[0], y1 = xp[1], y2 = xp[2];
 #pragma unroll
       for (int k = 0; k < C; k++) {
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
     float g[C];
 #pragma unroll
     for (int k = 0; k < C; k++) { cur = release_step(cur, (double)gs[k], P.rc); g[k] = f32r(cur); }
-    if (kb + C > 0) {
+    if (t >= T0 && kb + C > 0) {
       if (kb >= 0) store_chunk(go, n, kb, g);
       else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
     }
@@ -438,26 +440,32 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------- launchers
-int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev,
+int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
                       const double* gains_dev, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv);
-  else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv);
+  const int64_t seg = tuning().env_seg_tiles, warm = tuning().sc_warm_tiles;
+  const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  const unsigned nseg = (unsigned)((ntiles + seg - 1) / seg);
+  if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
+  else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
   int64_t bx = (n + (int64_t)kThreads * C - 1) / ((int64_t)kThreads * C); if (bx > 64) bx = 64;
   WAM_LAUNCH("k_sc_apply", k_sc_apply, dim3((unsigned)bx, (unsigned)(ntracks * nch)), dim3(kThreads), s, in, out, nch, n, plan_dev, gains_dev, (const float*)genv);
   return WAM_OK;
 }
 
-int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev,
+int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s) {
   if (n <= 0) return WAM_OK;
+  const int64_t seg = tuning().env_seg_tiles, warm = tuning().lim_warm_tiles;
   if (preserve) {
-    if (nch == 2) WAM_LAUNCH("k_lim_tm", k_lim_tm<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tm);
-    else WAM_LAUNCH("k_lim_tm", k_lim_tm<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tm);
+    const unsigned nseg = (unsigned)(((n + kTile - 1) / kTile + seg - 1) / seg);
+    if (nch == 2) WAM_LAUNCH("k_lim_tm", k_lim_tm<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, tm, seg, warm);
+    else WAM_LAUNCH("k_lim_tm", k_lim_tm<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, tm, seg, warm);
   }
   const float* tmi = preserve ? tm : nullptr;
-  if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv);
-  else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv);
+  const unsigned nsegg = (unsigned)(((n + L + kTile - 1) / kTile + seg - 1) / seg);
+  if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
+  else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
   WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, (const float*)genv, meter_dev, hopsums, hop_stride, peaks);
   return WAM_OK;
 }

@@ -51,6 +51,17 @@ void prof_end(hipStream_t s);
     WAM_HIP(hipGetLastError());                                          \
   } while (0)
 
+// Time-segmentation knobs (include/wam_synth.h: wam_tune).  Defaults are the production values; tests shrink them so
+// that short fixtures cross segment seams.
+struct Tuning {
+  int64_t dh_seg_frames = 512;    // de-harsh synthesis: frames per workgroup segment
+  int64_t dh_warm_frames = 48;    // frames re-run before a segment to rebuild the resonance EMA (0.7^48 = 4e-8) and the overlap-add ring
+  int64_t env_seg_tiles = 64;     // soft-clip / limiter envelopes: tiles (4096 samples) per segment
+  int64_t sc_warm_tiles = 3;      // soft-clip release: exp(-12288/480) = 8e-12
+  int64_t lim_warm_tiles = 25;    // limiter release 100 ms / peak follower 50 ms: exp(-102400/4800) = 5e-10
+};
+Tuning& tuning();
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace wam

@@ -97,6 +97,11 @@ def init(device=0):
     _check(lib().wam_init(C.c_int(device)))
 
 
+def tune(key, value=0):
+    """Time-segmentation knobs (include/wam_synth.h wam_tune); tune("reset") restores the defaults."""
+    _check(lib().wam_tune(key.encode(), C.c_int64(value)))
+
+
 def device_count():
     n = C.c_int(0)
     lib().wam_device_count(C.byref(n))
