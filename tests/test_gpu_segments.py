@@ -85,6 +85,25 @@ def test_chain_segments_long():
     ref, rres = O.render_chain(x, sr, s, "export")
     wam.tune("env_seg_tiles", 16)
     wam.tune("dh_seg_frames", 128)
+    wam.tune("fx_seg_tiles", 60)
     y, res = wam.render_full_chain(x, sr, s, "export")
     assert maxerr(y, ref) <= TOL
     assert abs(res.lufs - rres.lufs) <= 0.01
+
+
+def test_fx_segments(hot):
+    """exciter / tape warmth / punch: LTI state needs 2 warm-up tiles, the slow transient follower 48."""
+    sr, x0 = hot
+    x = [np.concatenate([c, c, c, c, c]) for c in x0]          # ~15 s = 176 tiles, so 48 warm-up tiles fit several times
+    cases = (("exciter", wam.apply_exciter, O.exciter), ("warmth", wam.apply_tape_warmth, O.warmth), ("punch", wam.apply_multiband_transient, O.punch))
+    for name, fn, ofn in cases:
+        ref = ofn(x, sr)
+        wam.tune("fx_seg_tiles", 1 << 20)
+        whole = fn(x, sr)
+        assert maxerr(whole, ref) <= TOL, name
+        for seg in (8, 50):
+            wam.tune("fx_seg_tiles", seg)
+            y = fn(x, sr)
+            assert maxerr(y, ref) <= TOL, (name, seg)
+            assert maxerr(y, whole) <= SEAM_TOL, (name, seg)
+        wam.tune("reset")

@@ -230,7 +230,7 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
   double* lufs_in_d = gains_d + T;
 
   // ---- buffer ping-pong: the last full-buffer write must land in `out`
-  int nwrites = (do_deharsh ? 1 : 0) + (do_exc ? 1 : 0) + ((do_warm || do_punch) ? 1 : 0);
+  int nwrites = (do_deharsh ? 1 : 0) + (do_exc ? 1 : 0) + (do_warm ? 1 : 0) + (do_punch ? 1 : 0);
   if (exp_mode) nwrites += 1 + (do_limit ? 2 : (do_norm ? 1 : 0));
   const float* src = in;
   float* bufs[2] = { B1.as<float>(), out };
@@ -253,12 +253,17 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
-  if (do_warm) { rc = prog(0.45, "Applying multiband saturation..."); if (rc) return rc; }
-  if (do_punch) { rc = prog(0.55, "Applying multiband transient..."); if (rc) return rc; }
-  if (do_warm || do_punch) {
-    if (do_warm) { rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream); if (rc) return rc; }
+  if (do_warm) {
+    rc = prog(0.45, "Applying multiband saturation..."); if (rc) return rc;
+    rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream); if (rc) return rc;
     float* dst = next_dst();
-    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, do_warm, do_punch, do_warm ? wenv.as<float>() : nullptr, pending_gain, stream); if (rc) return rc;
+    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 1, 0, wenv.as<float>(), pending_gain, stream); if (rc) return rc;
+    src = dst; pending_gain = 1.0;
+  }
+  if (do_punch) {
+    rc = prog(0.55, "Applying multiband transient..."); if (rc) return rc;
+    float* dst = next_dst();
+    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 0, 1, nullptr, pending_gain, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
 

@@ -16,7 +16,7 @@ __device__ __forceinline__ void biquad_extra2(const double y[C], const double x[
 }
 
 __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ in, float* __restrict__ out, int64_t n,
-                                                      const HeavyPlan* __restrict__ hp, double pre_gain) {
+                                                      const HeavyPlan* __restrict__ hp, double pre_gain, int64_t seg_tiles, int64_t warm) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[1][kCtxFloats];
   const int64_t chan = blockIdx.x;
@@ -27,8 +27,12 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
   biquad_lane_power(hp->exc_hp, lane_id(), P1);
   double Sa[2] = {0, 0}, Sb[2] = {0, 0};
   const double mix = 0.15 / 100, drive = 0.5, bias = 0.2;     // constants.js:36-42, exciter.js:88
+  // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early: the only state is two 6 kHz high-passes
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const int64_t T0 = (int64_t)blockIdx.y * seg_tiles;
+  int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
+  const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  for (int64_t t = Tw; t < T1; t++) {
     const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     float v[C];
@@ -41,7 +45,11 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     }
     const float last[2] = { v[C - 2], v[C - 1] };
     float pv[2];
-    prev_ctx<2>(last, pv, ctx[0], (int)(t & 1), t == 0);
+    prev_ctx<2>(last, pv, ctx[0], (int)(t & 1), t == Tw);
+    if (t == Tw && Tw > 0 && threadIdx.x == 0) {          // a later segment starts from the samples in memory
+      pv[0] = x[base - 2]; pv[1] = x[base - 1];
+      if (pre_gain != 1.0) { pv[0] = f32r((double)pv[0] * pre_gain); pv[1] = f32r((double)pv[1] * pre_gain); }
+    }
     double xin[C], d[C];
 #pragma unroll
     for (int k = 0; k < C; k++) { xin[k] = v[k]; d[k] = v[k]; }
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
       const double wet = (wetA + wetB) * 0.5;
       o[k] = f32r((double)v[k] + wet * mix);
     }
-    store_chunk(y, n, base, o);
+    if (t >= T0) store_chunk(y, n, base, o);
   }
 }
 
@@ -124,12 +132,14 @@ __global__ void k_warm_env(const unsigned* __restrict__ winpeak, int ntracks, in
 }
 
 // LR4 three-band split of a chunk (multiband-saturation.js:125-148 / multiband-transient.js:94-132).
-struct SplitState { double P[4][4]; double S[8][2]; };
+struct SplitState { double P[4][64][4]; double S[8][2]; };      // lives in LDS
 __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, const Biquad& hp1, const Biquad& lp2, const Biquad& hp2) {
-  biquad_lane_power(lp1, lane_id(), st.P[0]); biquad_lane_power(hp1, lane_id(), st.P[1]);
-  biquad_lane_power(lp2, lane_id(), st.P[2]); biquad_lane_power(hp2, lane_id(), st.P[3]);
-#pragma unroll
-  for (int i = 0; i < 8; i++) { st.S[i][0] = 0; st.S[i][1] = 0; }
+  if (wave_id() == 0) {
+    biquad_lane_power(lp1, lane_id(), st.P[0][lane_id()]); biquad_lane_power(hp1, lane_id(), st.P[1][lane_id()]);
+    biquad_lane_power(lp2, lane_id(), st.P[2][lane_id()]); biquad_lane_power(hp2, lane_id(), st.P[3][lane_id()]);
+  }
+  if (threadIdx.x < 16) st.S[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+  __syncthreads();
 }
 // Bands are handed to `consume(band_index, float band[C])` one at a time (low, mid, high) so that only one band
 // is live in registers while it is processed.
@@ -141,20 +151,20 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   // low = lp1(lp1(x))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = v[k];
-  biquad_chunk(d, xm1, xm2, lp1, st.P[0], st.S[0][0], st.S[0][1], slots.next(), s0, s1);
+  biquad_chunk_lds(d, xm1, xm2, lp1, &st.P[0][0][0], st.S[0], slots.next(), s0, s1);
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), lp1, st.P[0], st.S[1][0], st.S[1][1], slots.next(), t0, t1);
+  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), lp1, &st.P[0][0][0], st.S[1], slots.next(), t0, t1);
 #pragma unroll
   for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
   consume(0, band);
   // midHigh = hp1(hp1(x))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = v[k];
-  biquad_chunk(d, xm1, xm2, hp1, st.P[1], st.S[2][0], st.S[2][1], slots.next(), s0, s1);
+  biquad_chunk_lds(d, xm1, xm2, hp1, &st.P[1][0][0], st.S[2], slots.next(), s0, s1);
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), hp1, st.P[1], st.S[3][0], st.S[3][1], slots.next(), t0, t1);
+  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), hp1, &st.P[1][0][0], st.S[3], slots.next(), t0, t1);
   float mh[C];
 #pragma unroll
   for (int k = 0; k < C; k++) mh[k] = f32r(d[k]);
@@ -162,20 +172,20 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   // mid = lp2(lp2(mh))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = mh[k];
-  biquad_chunk(d, mh1, mh2, lp2, st.P[2], st.S[4][0], st.S[4][1], slots.next(), s0, s1);
+  biquad_chunk_lds(d, mh1, mh2, lp2, &st.P[2][0][0], st.S[4], slots.next(), s0, s1);
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), lp2, st.P[2], st.S[5][0], st.S[5][1], slots.next(), t0, t1);
+  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), lp2, &st.P[2][0][0], st.S[5], slots.next(), t0, t1);
 #pragma unroll
   for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
   consume(1, band);
   // high = hp2(hp2(mh))
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = mh[k];
-  biquad_chunk(d, mh1, mh2, hp2, st.P[3], st.S[6][0], st.S[6][1], slots.next(), s0, s1);
+  biquad_chunk_lds(d, mh1, mh2, hp2, &st.P[3][0][0], st.S[6], slots.next(), s0, s1);
 #pragma unroll
   for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), hp2, st.P[3], st.S[7][0], st.S[7][1], slots.next(), t0, t1);
+  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), hp2, &st.P[3][0][0], st.S[7], slots.next(), t0, t1);
 #pragma unroll
   for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
   consume(2, band);
@@ -185,9 +195,9 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
 // two launches (the second in place on the first's output: a tile is fully read before it is written), which costs
 // 8 B per sample-channel of extra traffic on a kernel that is bound by f64 issue, not by HBM.
 template <bool do_warm, bool do_punch>
-__global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float* out, int nch, int64_t n,
+__global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, float* out, int nch, int64_t n,
                                                          const HeavyPlan* __restrict__ hp,
-                                                         const float* __restrict__ env, double pre_gain) {
+                                                         const float* __restrict__ env, double pre_gain, int64_t seg_tiles, int64_t warm) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[2][kCtxFloats];
   const int64_t chan = blockIdx.x;
@@ -196,17 +206,23 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float*
   float* y = out + chan * n;
   const float* ev = env ? env + trk * hp->w_nw : nullptr;
   LdsSlots slots(lds_scan);
-  SplitState sw, sp;
+  __shared__ SplitState sw_s;                 // one instantiation uses one of the two
+  SplitState& sw = sw_s; SplitState& sp = sw_s;
   if (do_warm) split_init(sw, hp->w_lp1, hp->w_hp1, hp->w_lp2, hp->w_hp2);
   if (do_punch) split_init(sp, hp->p_lp1, hp->p_hp1, hp->p_lp2, hp->p_hp2);
   double Sf[3] = {0, 0, 0}, Ss[3] = {0, 0, 0}, Sg[3] = {1, 1, 1};
   const double Psm = onepole_lane_power(hp->p_smooth, lane_id());
   // bypass-envelope window of this thread's chunk start, advanced tile by tile without divisions
-  const int64_t ws = hp->w_ws > 0 ? hp->w_ws : 1;
-  int64_t win = ((int64_t)threadIdx.x * C) / ws, wpos = ((int64_t)threadIdx.x * C) % ws;
-  const int64_t tile_q = kTile / ws, tile_r = kTile % ws;
+  // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early (LR4 filters: 2 tiles; the slow transient
+  // follower's 250 ms release: 48 tiles)
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const int64_t T0 = (int64_t)blockIdx.y * seg_tiles;
+  int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
+  const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  const int64_t ws = hp->w_ws > 0 ? hp->w_ws : 1;
+  int64_t win = (Tw * kTile + (int64_t)threadIdx.x * C) / ws, wpos = (Tw * kTile + (int64_t)threadIdx.x * C) % ws;
+  const int64_t tile_q = kTile / ws, tile_r = kTile % ws;
+  for (int64_t t = Tw; t < T1; t++) {
     const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
@@ -219,7 +235,11 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float*
     if (do_warm) {
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
-      prev_ctx<2>(last, pv, ctx[0], par, t == 0);
+      prev_ctx<2>(last, pv, ctx[0], par, t == Tw);
+      if (t == Tw && Tw > 0 && threadIdx.x == 0) {
+        pv[0] = x[base - 2]; pv[1] = x[base - 1];
+        if (pre_gain != 1.0) { pv[0] = f32r((double)pv[0] * pre_gain); pv[1] = f32r((double)pv[1] * pre_gain); }
+      }
       // envelope[min(floor(i / windowSamples), numWindows - 1)] (multiband-saturation.js:335-337); windowSamples >= C
       // (checked by enqueue_warm_env), so a chunk crosses at most one window boundary
       const int64_t nwl = P.w_nw - 1;
@@ -248,22 +268,26 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float*
     if (do_punch) {
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
-      prev_ctx<2>(last, pv, ctx[1], par, t == 0);
+      prev_ctx<2>(last, pv, ctx[1], par, t == Tw);
+      if (t == Tw && Tw > 0 && threadIdx.x == 0) {
+        pv[0] = x[base - 2]; pv[1] = x[base - 1];
+        if (pre_gain != 1.0) { pv[0] = f32r((double)pv[0] * pre_gain); pv[1] = f32r((double)pv[1] * pre_gain); }
+      }
       double acc[C];
       auto transient = [&](int b, const float band[C]) {
         // processTransients, multiband-transient.js:194-263
         const double fA = P.pf_A[b], fR = P.pf_R[b], sA = P.ps_A[b], sR = P.ps_R[b], tg = P.p_tg[b] - 1, sg = P.p_sg[b] - 1;
         const double osm = 1 - P.p_smooth.c;
-        double a[C];
+        float a[C];                           // rectified input (f32 values, widened where used)
 #pragma unroll
-        for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabs((double)band[k]) : 0.0;
+        for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabsf(band[k]) : 0.0f;
         double fe = follower_solve(a, fA, fR, Sf[b], slots.next());
         double se = follower_solve(a, sA, sR, Ss[b], slots.next());
         double u[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-          fe = follower_step(fe, a[k], fA, fR);
-          se = follower_step(se, a[k], sA, sR);
+          fe = follower_step(fe, (double)a[k], fA, fR);
+          se = follower_step(se, (double)a[k], sA, sR);
           const double diff = fe - se;
           // strength = min(|diff| / max-guard(slowEnv, 1e-4), 1); gain towards the transient or the sustain target
           const double st = fmin(fabs(diff) / (se > 0.0001 ? se : 0.0001), 1.0);
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float*
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r(acc[k]);
     }
-    store_chunk(y, n, base, v);
+    if (t >= T0) store_chunk(y, n, base, v);
     win += tile_q; wpos += tile_r;
     if (wpos >= ws) { wpos -= ws; win++; }
   }
@@ -291,7 +315,9 @@ __global__ __launch_bounds__(kThreads) void k_warm_punch(const float* in, float*
 // ---------------------------------------------------------------------------- launchers
 int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  WAM_LAUNCH("k_exciter", k_exciter, dim3(ntracks * nch), dim3(kThreads), s, in, out, n, plan_dev, pre_gain);
+  const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().lti_warm_tiles;
+  const int64_t seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+  WAM_LAUNCH("k_exciter", k_exciter, dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, n, plan_dev, pre_gain, seg, warm);
   return WAM_OK;
 }
 
@@ -312,10 +338,16 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
                        const float* env, double pre_gain, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  if (do_warm) WAM_LAUNCH("k_warm", (k_warm_punch<true, false>), dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain);
+  if (do_warm && do_punch) { set_error("enqueue_warm_punch: one stage per call (segments read their neighbours' input: no in-place chaining)"); return WAM_ERR_INVALID; }
+  if (in == out) { set_error("enqueue_warm_punch: in-place operation is not supported"); return WAM_ERR_INVALID; }
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  if (do_warm) {
+    const int64_t warm = tuning().lti_warm_tiles, seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+    WAM_LAUNCH("k_warm", (k_warm_punch<true, false>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
+  }
   if (do_punch) {
-    const float* src = do_warm ? out : in;
-    WAM_LAUNCH("k_punch", (k_warm_punch<false, true>), dim3(ntracks * nch), dim3(kThreads), s, src, out, nch, n, plan_dev, env, do_warm ? 1.0 : pre_gain);
+    const int64_t warm = tuning().punch_warm_tiles, seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+    WAM_LAUNCH("k_punch", (k_warm_punch<false, true>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
   }
   return WAM_OK;
 }

@@ -59,8 +59,24 @@ struct Tuning {
   int64_t env_seg_tiles = 64;     // soft-clip / limiter envelopes: tiles (4096 samples) per segment
   int64_t sc_warm_tiles = 3;      // soft-clip release: exp(-12288/480) = 8e-12
   int64_t lim_warm_tiles = 25;    // limiter release 100 ms / peak follower 50 ms: exp(-102400/4800) = 5e-10
+  int64_t fx_seg_tiles = 0;       // exciter / warmth / punch: tiles per segment, 0 = pick_segment_tiles()
+  int64_t lti_warm_tiles = 2;     // kernels whose only state is LTI filters >= 30 Hz: e^-11 per tile at 30 Hz, e^-75 at 200 Hz
+  int64_t punch_warm_tiles = 48;  // slow transient follower, 250 ms release: exp(-196608/12000) = 8e-8
 };
 Tuning& tuning();
+
+// Tiles per segment for the kernels that walk a (track, channel) in time order: enough segments that the launch has
+// about `want_wgs` workgroups, but never so short that the warm-up re-run costs more than a quarter of the work.
+inline int64_t pick_segment_tiles(int64_t walkers, int64_t ntiles, int64_t warm, int64_t override_tiles, int64_t want_wgs = 2048) {
+  if (override_tiles > 0) return override_tiles;
+  if (ntiles < 1) return 1;
+  int64_t nseg = (want_wgs + walkers - 1) / (walkers > 0 ? walkers : 1);
+  if (nseg < 1) nseg = 1;
+  int64_t seg = (ntiles + nseg - 1) / nseg;
+  if (seg < 4 * warm) seg = 4 * warm;
+  if (seg < 8) seg = 8;
+  return seg;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

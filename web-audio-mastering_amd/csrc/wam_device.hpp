@@ -174,6 +174,59 @@ __device__ __forceinline__ void biquad_chunk(double x[C], double xm1, double xm2
   }
 }
 
+// ---- the same stage with its carried state in LDS -------------------------------------
+// Kernels that run many biquads per tile (the LR4 band splits) keep the lane powers M^lane ([64][4] doubles per
+// distinct filter) and the tile carries ([2] doubles per filter instance) in LDS instead of registers: 12 VGPRs per
+// instance that would otherwise be live across the whole tile loop.  Plds/Slds are written once at kernel start
+// (and Slds by thread 0 after each scan); a barrier separates every write from the next read.
+__device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double xm2, const Biquad& q, const double* Plds, double* Slds,
+                                                 double* lds, double& s0, double& s1) {
+  const double b0 = q.b0, b1 = q.b1, b2 = q.b2, a1 = q.a1, a2 = q.a2;
+  double p1 = 0, p2 = 0, i1 = xm1, i2 = xm2;
+#pragma unroll
+  for (int n = 0; n < C; n++) {
+    const double xi = x[n];
+    const double w = b0 * xi + b1 * i1 + b2 * i2;
+    i2 = i1; i1 = xi;
+    x[n] = w;
+    const double y = w - a1 * p1 - a2 * p2;
+    p2 = p1; p1 = y;
+  }
+  double e0 = p1, e1 = p2;
+  const int lane = lane_id(), wave = wave_id();
+  const double S0 = Slds[0], S1 = Slds[1];           // read before the barrier below; rewritten after it
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int d = 1 << k;
+    const double t0 = __shfl_up(e0, d), t1 = __shfl_up(e1, d);
+    if (lane >= d) { e0 += q.Mp[k][0] * t0 + q.Mp[k][1] * t1; e1 += q.Mp[k][2] * t0 + q.Mp[k][3] * t1; }
+  }
+  if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
+  double x0 = __shfl_up(e0, 1), x1 = __shfl_up(e1, 1);
+  if (lane == 0) { x0 = 0; x1 = 0; }
+  __syncthreads();
+  double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    const double c0 = lds[2 * w], c1 = lds[2 * w + 1];
+    const double n0 = q.Mp[6][0] * w0 + q.Mp[6][1] * w1 + c0;
+    const double n1 = q.Mp[6][2] * w0 + q.Mp[6][3] * w1 + c1;
+    w0 = n0; w1 = n1;
+    if (w + 1 == wave) { my0 = w0; my1 = w1; }
+  }
+  if (threadIdx.x == 0) { Slds[0] = w0; Slds[1] = w1; }
+  const double* P = Plds + 4 * lane;
+  s0 = x0 + P[0] * my0 + P[1] * my1;
+  s1 = x1 + P[2] * my0 + P[3] * my1;
+  p1 = s0; p2 = s1;
+#pragma unroll
+  for (int n = 0; n < C; n++) {
+    const double y = x[n] - a1 * p1 - a2 * p2;
+    p2 = p1; p1 = y;
+    x[n] = y;
+  }
+}
+
 // ---- first-order scan ----------------------------------------------------------
 __device__ __forceinline__ void scan1(double& e, const OnePole& q, double Pl, double& S, double* lds) {
   const int lane = lane_id(), wave = wave_id();
@@ -267,7 +320,8 @@ __device__ __forceinline__ double solve_piecewise(Run run, double guess, double&
 // Branchy attack/release follower (dsp-worker.js:1308-1312, :345-349;
 // multiband-transient.js:219-230): e' = (a > e) ? A e + (1-A) a : R e + (1-R) a.
 // a[] = rectified input of the chunk.  Returns the chunk's true start value.
-__device__ __forceinline__ double follower_solve(const double a[C], double A, double R, double& S, double* lds) {
+template <class T>
+__device__ __forceinline__ double follower_solve(const T a[C], double A, double R, double& S, double* lds) {
   // (al, be) are functions of the branch pattern only (never of e0's low bits), so the fixed-point test of
   // solve_piecewise terminates as soon as the pattern is stable.  The envelope itself is materialised by follower_step.
   auto run = [&](double e0, double& al, double& be) {
@@ -275,8 +329,9 @@ __device__ __forceinline__ double follower_solve(const double a[C], double A, do
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double e = fma(al, e0, be);
-      const double c = (a[n] > e) ? A : R;
-      be = fma(c, be - a[n], a[n]);          // = c be + (1 - c) a
+      const double an = (double)a[n];
+      const double c = (an > e) ? A : R;
+      be = fma(c, be - an, an);              // = c be + (1 - c) a
       al = c * al;
     }
   };
