@@ -107,3 +107,39 @@ def test_fx_segments(hot):
             assert maxerr(y, ref) <= TOL, (name, seg)
             assert maxerr(y, whole) <= SEAM_TOL, (name, seg)
         wam.tune("reset")
+
+
+def test_meter_segments_bit_exact_gating():
+    """Segmented metering: every hop sum has one owner workgroup, so block energies agree with the unsegmented walk
+    to rounding and the gate masks are identical."""
+    sr = 48000
+    x = O.synth(2, 2, 30 * sr + 4321, sr, {"amp": 0.9, "quietFrom": 5 * sr, "quietTo": 12 * sr, "quietGain": 0.004})
+    ref = O.measure_lufs(x, sr, detail=True)
+    wam.tune("meter_seg_tiles", 1 << 20)
+    l0, b0, m0 = wam.measure_lufs(x, sr, detail=True)
+    p0 = wam.find_true_peak(x)
+    for seg in (8, 13, 40):
+        wam.tune("meter_seg_tiles", seg)
+        l1, b1, m1 = wam.measure_lufs(x, sr, detail=True)
+        assert np.array_equal(m1, m0) and np.array_equal(m1, ref[2])
+        assert np.max(np.abs(b1 - b0) / np.maximum(b0, 1e-30)) < 1e-9
+        assert abs(l1 - l0) < 1e-9 and abs(l1 - ref[0]) < 1e-6
+        assert abs(wam.find_true_peak(x) - p0) < 1e-12
+
+
+def test_front_and_limiter_apply_segments(hot):
+    sr, x0 = hot
+    x = [np.concatenate([c, c, c, c, c, c, c, c]) for c in x0]          # ~24 s = 282 tiles
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=False, addAir=False, tapeWarmth=False, addPunch=False, glueCompression=True,
+             eqLow=1, eqMid=-1, eqHigh=2, cutMud=True, stereoWidth=130)
+    ref, rres = O.render_chain(x, sr, s, "export")
+    wam.tune("meter_seg_tiles", 1 << 20)
+    whole, wres = wam.render_full_chain(x, sr, s, "export")
+    assert maxerr(whole, ref) <= TOL
+    for seg in (60, 110):
+        wam.tune("meter_seg_tiles", seg)
+        y, res = wam.render_full_chain(x, sr, s, "export")
+        assert maxerr(y, ref) <= TOL
+        assert maxerr(y, whole) <= 5e-7
+        assert abs(res.lufs - wres.lufs) < 1e-6 and abs(res.true_peak_db - wres.true_peak_db) < 1e-6
+        assert abs(res.lufs - rres.lufs) <= 0.01

@@ -35,7 +35,7 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
 };
 
 // ---- launchers (chain_*.hip).  All buffers are device pointers, layout [ntracks][nch][n]. ----
-int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
+int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s);
 
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,

@@ -136,7 +136,7 @@ static int run_front_only(const float* const* ch, int nch, int64_t n, double sr,
   rc = ensure_device(); if (rc) return rc;
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan; rc = upload_plan(fp, plan, nullptr); if (rc) return rc;
-  rc = enqueue_front(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<FrontPlan>(), nullptr, nullptr, 0, nullptr, 1.0, nullptr);
+  rc = enqueue_front(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<FrontPlan>(), fp.do_glue, nullptr, nullptr, 0, nullptr, 1.0, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
@@ -288,7 +288,7 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     {
       float* dst = next_dst();
       if (fp.do_meter) WAM_HIP(hipMemsetAsync(M1.hopsums, 0, M1.hopsums_bytes, stream));
-      rc = enqueue_front(src, dst, T, nch, n, fp_d, M1.plan, M1.hopsums, M1.hop_stride, M1.peaks, pending_gain, stream); if (rc) return rc;
+      rc = enqueue_front(src, dst, T, nch, n, fp_d, fp.do_glue, M1.plan, M1.hopsums, M1.hop_stride, M1.peaks, pending_gain, stream); if (rc) return rc;
       src = dst; pending_gain = 1.0;
       if (fp.do_meter) { rc = enqueue_gate(mp, T, M1, stream); if (rc) return rc; final_meter = &M1; }
     }

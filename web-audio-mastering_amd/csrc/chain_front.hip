@@ -14,7 +14,7 @@ template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                     const FrontPlan* __restrict__ fp, const MeterPlan* __restrict__ mp,
                                                     double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
-                                                    double pre_gain) {
+                                                    double pre_gain, int64_t seg_tiles, int64_t warm) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ double lds_meter[NCH][kMeterLds];
   __shared__ float ctx[NCH * 9 + 1][kCtxFloats];   // per channel: hpf, 6 eq, lpf->eq, meter; + side
@@ -35,11 +35,15 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
   biquad_lane_power(P.side_hp, lane, Pside);
   Plpf = onepole_lane_power(P.lpf18, lane);
   double Shpf[NCH][2] = {}, Slpf[NCH] = {}, Seq[NCH][6][2] = {}, Sside[2] = {0, 0}, Senv = 0;
-  MeterState ms[NCH];
-  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_init(ms[c], *mp, 0);
-
+  // time segment (blockIdx.y): tiles [T0, T1) entered `warm` tiles early with cold state; the warm-up re-run rebuilds
+  // the filters (30 Hz high-pass: e^-11 per tile) and, when the glue compressor is on, its 250 ms release follower
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, P.do_meter ? mp->hop : 0, P.do_meter ? mp->nhops : 0);
+  MeterState ms[NCH];
+  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_init(ms[c], *mp, sg.Tw * kTile, &sg);
+
+  for (int64_t t = sg.Tw; t < sg.T1; t++) {
+    const bool first = t == sg.Tw;
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
       if (P.do_hpf) {
         const float last[2] = { v[C - 2], v[C - 1] };
         float pv[2];
-        prev_ctx<2>(last, pv, ctx[c * 9 + 0], par, t == 0);
+        prev_ctx<2>(last, pv, ctx[c * 9 + 0], par, first);
         double s0, s1;
         biquad_chunk(d, pv[1], pv[0], P.hpf30, Phpf, Shpf[c][0], Shpf[c][1], slots.next(), s0, s1);
 #pragma unroll
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
         if (!have_nb) {
           const float last[2] = { f32r(d[C - 2]), f32r(d[C - 1]) };
           float pv[2];
-          prev_ctx<2>(last, pv, ctx[c * 9 + 1 + b], par, t == 0);
+          prev_ctx<2>(last, pv, ctx[c * 9 + 1 + b], par, first);
           nb1 = pv[1]; nb2 = pv[0];
         }
         double s0, s1;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
       if (P.bass_mono) {
         const float last[2] = { side[C - 2], side[C - 1] };
         float pv[2];
-        prev_ctx<2>(last, pv, ctx[NCH * 9], par, t == 0);
+        prev_ctx<2>(last, pv, ctx[NCH * 9], par, first);
         double d[C];
 #pragma unroll
         for (int k = 0; k < C; k++) d[k] = side[k];
@@ -157,11 +161,11 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
 
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      store_chunk(y[c], n, base, w[c]);
+      if (t >= sg.T0) store_chunk(y[c], n, base, w[c]);
       if (P.do_meter) {
         const float last[3] = { w[c][C - 3], w[c][C - 2], w[c][C - 1] };
         float xp[3];
-        prev_ctx<3>(last, xp, ctx[c * 9 + 8], par, t == 0);
+        prev_ctx<3>(last, xp, ctx[c * 9 + 8], par, first);
         meter_chunk(w[c], xp, base, tile_base, n, *mp, ms[c], lds_meter[c], hopsums + (trk * NCH + c) * hop_stride);
       }
     }
@@ -169,11 +173,15 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
   if (P.do_meter) for (int c = 0; c < NCH; c++) meter_finish(ms[c], lds_meter[c], peaks + trk * NCH + c);
 }
 
-int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev,
+int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  if (nch == 2) WAM_LAUNCH("k_front", k_front<2>, dim3(ntracks), dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain);
-  else WAM_LAUNCH("k_front", k_front<1>, dim3(ntracks), dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  const int64_t warm = do_glue ? tuning().glue_warm_tiles : tuning().meter_warm_tiles;
+  const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().meter_seg_tiles);
+  const dim3 grid(ntracks, (unsigned)((ntiles + seg - 1) / seg));
+  if (nch == 2) WAM_LAUNCH("k_front", k_front<2>, grid, dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain, seg, warm);
+  else WAM_LAUNCH("k_front", k_front<1>, grid, dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain, seg, warm);
   return WAM_OK;
 }
 

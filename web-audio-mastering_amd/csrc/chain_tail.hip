@@ -391,7 +391,7 @@ __device__ __forceinline__ double soft_knee_curve(double s, double ceiling, doub
 __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
                                                         const LimiterPlan* __restrict__ lp, const float* __restrict__ genv,
                                                         const MeterPlan* __restrict__ mp, double* __restrict__ hopsums, int64_t hop_stride,
-                                                        double* __restrict__ peaks) {
+                                                        double* __restrict__ peaks, int64_t seg_tiles, int64_t warm) {
   __shared__ double lds_meter[kMeterLds];
   __shared__ float ctx[2][kCtxFloats];
   const LimiterPlan& P = *lp;
@@ -400,10 +400,12 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
   const float* x = in + chan * n;
   const float* g = genv + trk * n;
   float* y = out + chan * n;
-  MeterState ms;
-  if (mp) meter_init(ms, *mp, 0);
+  // time segment (blockIdx.y); the only carried state is the fused meter's filters and six samples of context
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, mp ? mp->hop : 0, mp ? mp->nhops : 0);
+  MeterState ms;
+  if (mp) meter_init(ms, *mp, sg.Tw * kTile, &sg);
+  for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
@@ -414,7 +416,11 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
     for (int k = 0; k < C; k++) s[k] = f32r((double)v[k] * (double)gv[k]);
     const float last[3] = { s[C - 3], s[C - 2], s[C - 1] };
     float sp[3];
-    prev_ctx<3>(last, sp, ctx[0], par, t == 0);
+    prev_ctx<3>(last, sp, ctx[0], par, t == sg.Tw);
+    if (t == sg.Tw && sg.Tw > 0 && threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) sp[j] = f32r((double)x[base - 3 + j] * (double)g[base - 3 + j]);
+    }
     float o[C];
     double y0 = sp[0], y1 = sp[1], y2 = sp[2];
 #pragma unroll
@@ -428,11 +434,11 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
       o[k] = f32r(soft_knee_curve(r, P.ceil_lin, P.knee_start));
       y0 = y1; y1 = y2; y2 = y3;
     }
-    store_chunk(y, n, base, o);
+    if (t >= sg.T0) store_chunk(y, n, base, o);
     if (mp) {
       const float lo[3] = { o[C - 3], o[C - 2], o[C - 1] };
       float op[3];
-      prev_ctx<3>(lo, op, ctx[1], par, t == 0);
+      prev_ctx<3>(lo, op, ctx[1], par, t == sg.Tw);
       meter_chunk(o, op, base, tile_base, n, *mp, ms, lds_meter, hopsums + chan * hop_stride);
     }
   }
@@ -466,7 +472,12 @@ int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntr
   const unsigned nsegg = (unsigned)(((n + L + kTile - 1) / kTile + seg - 1) / seg);
   if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
   else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
-  WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch), dim3(kThreads), s, in, out, nch, n, plan_dev, (const float*)genv, meter_dev, hopsums, hop_stride, peaks);
+  {
+    const int64_t ntiles = (n + kTile - 1) / kTile, mwarm = tuning().meter_warm_tiles;
+    const int64_t mseg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, mwarm, tuning().meter_seg_tiles);
+    WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch, (unsigned)((ntiles + mseg - 1) / mseg)), dim3(kThreads), s, in, out, nch, n, plan_dev,
+               (const float*)genv, meter_dev, hopsums, hop_stride, peaks, mseg, mwarm);
+  }
   return WAM_OK;
 }
 

@@ -13,23 +13,26 @@
 namespace wam {
 
 __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in, int64_t n, const MeterPlan* __restrict__ plan,
-                                                    double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks) {
+                                                    double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
+                                                    int64_t seg_tiles, int64_t warm) {
   __shared__ double lds[kMeterLds];
   __shared__ float ctx[2 * (kThreads + 1) * 3];
   const MeterPlan& pl = *plan;
   const int64_t chan = blockIdx.x;
   const float* x = in + chan * n;
   double* hs = hopsums + chan * hop_stride;
-  MeterState m;
-  meter_init(m, pl, 0);
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, pl.hop, pl.nhops);
+  MeterState m;
+  meter_init(m, pl, sg.Tw * kTile, &sg);
+  for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     float v[C], xp[3];
     load_chunk(x, n, base, v);
     const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
-    prev_context<3>(last, xp, ctx, (int)(t & 1), t == 0);
+    prev_context<3>(last, xp, ctx, (int)(t & 1), t == sg.Tw);
+    if (t == sg.Tw && sg.Tw > 0 && threadIdx.x == 0) { xp[0] = x[base - 3]; xp[1] = x[base - 2]; xp[2] = x[base - 1]; }
     meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hs);
   }
   meter_finish(m, lds, peaks + chan);
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in
 // x * gain -> out (optional), metered.  One workgroup per (track, channel).  gains: per track or NULL.
 __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
                                                          const double* __restrict__ gains, const MeterPlan* __restrict__ plan,
-                                                         double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks) {
+                                                         double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
+                                                         int64_t seg_tiles, int64_t warm) {
   __shared__ double lds[kMeterLds];
   __shared__ float ctx[kCtxFloats];
   const MeterPlan& pl = *plan;
@@ -46,10 +50,11 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
   const double G = gains ? gains[chan / nch] : 1.0;
   const float* x = in + chan * n;
   float* y = out ? out + chan * n : nullptr;
-  MeterState m;
-  meter_init(m, pl, 0);
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  for (int64_t t = 0; t < ntiles; t++) {
+  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, pl.hop, pl.nhops);
+  MeterState m;
+  meter_init(m, pl, sg.Tw * kTile, &sg);
+  for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     float v[C], xp[3];
@@ -58,9 +63,13 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * G);       // normalizer.js:66-72
     }
-    if (y) store_chunk(y, n, base, v);
+    if (y && t >= sg.T0) store_chunk(y, n, base, v);
     const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
-    prev_ctx<3>(last, xp, ctx, (int)(t & 1), t == 0);
+    prev_ctx<3>(last, xp, ctx, (int)(t & 1), t == sg.Tw);
+    if (t == sg.Tw && sg.Tw > 0 && threadIdx.x == 0) {
+      xp[0] = x[base - 3]; xp[1] = x[base - 2]; xp[2] = x[base - 1];
+      if (gains) { xp[0] = f32r((double)xp[0] * G); xp[1] = f32r((double)xp[1] * G); xp[2] = f32r((double)xp[2] * G); }
+    }
     meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hopsums + chan * hop_stride);
   }
   meter_finish(m, lds, peaks + chan);
@@ -183,8 +192,10 @@ void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void*
   char* p = (char*)scratch;
   s->hop_stride = pl.nhops + 4;
   s->plan = (MeterPlan*)p; p += align_up(sizeof(MeterPlan), 256);
-  s->hopsums = (double*)p; s->hopsums_bytes = sizeof(double) * (size_t)s->hop_stride * ntracks * pl.nch; p += align_up(s->hopsums_bytes, 256);
+  const size_t hs_bytes = sizeof(double) * (size_t)s->hop_stride * ntracks * pl.nch;
+  s->hopsums = (double*)p; p += align_up(hs_bytes, 256);
   s->peaks = (double*)p; p += align_up(sizeof(double) * (size_t)ntracks * pl.nch, 256);
+  s->hopsums_bytes = (size_t)((char*)s->peaks - (char*)s->hopsums) + sizeof(double) * (size_t)ntracks * pl.nch;   // one memset zeroes hop sums AND peaks
   s->blocks = (double*)p; p += align_up(sizeof(double) * (size_t)(pl.nblocks > 0 ? pl.nblocks : 1) * ntracks, 256);
   s->gate = (GateOut*)p; p += align_up(sizeof(GateOut) * (size_t)ntracks, 256);
   s->mask = want_mask ? (uint8_t*)p : nullptr;
@@ -199,9 +210,10 @@ int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_
                        const MeterScratch& s, hipStream_t stream) {
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
   if (n > 0) {
-    WAM_LAUNCH("k_gain_meter", k_gain_meter, dim3(ntracks * nch), dim3(kThreads), stream, in, out, nch, n, gains, (const MeterPlan*)s.plan, s.hopsums, s.hop_stride, s.peaks);
-  } else {
-    WAM_HIP(hipMemsetAsync(s.peaks, 0, sizeof(double) * (size_t)ntracks * nch, stream));
+    const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().meter_warm_tiles;
+    const int64_t seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().meter_seg_tiles);
+    WAM_LAUNCH("k_gain_meter", k_gain_meter, dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), stream, in, out, nch, n, gains,
+               (const MeterPlan*)s.plan, s.hopsums, s.hop_stride, s.peaks, seg, warm);
   }
   return enqueue_gate(pl, ntracks, s, stream);
 }
@@ -215,9 +227,10 @@ int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t
   WAM_HIP(hipMemcpyAsync(s.plan, &pl, sizeof(MeterPlan), hipMemcpyHostToDevice, stream));
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
   if (n > 0) {
-    WAM_LAUNCH("k_meter", k_meter, dim3(ntracks * pl.nch), dim3(kThreads), stream, in_dev, n, s.plan, s.hopsums, s.hop_stride, s.peaks);
-  } else {
-    WAM_HIP(hipMemsetAsync(s.peaks, 0, sizeof(double) * (size_t)ntracks * pl.nch, stream));
+    const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().meter_warm_tiles;
+    const int64_t seg = pick_segment_tiles((int64_t)ntracks * pl.nch, ntiles, warm, tuning().meter_seg_tiles);
+    WAM_LAUNCH("k_meter", k_meter, dim3(ntracks * pl.nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), stream, in_dev, n, s.plan, s.hopsums,
+               s.hop_stride, s.peaks, seg, warm);
   }
   return enqueue_gate(pl, ntracks, s, stream);
 }

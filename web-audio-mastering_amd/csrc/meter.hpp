@@ -29,9 +29,33 @@ struct MeterState {            // carried across tiles, per channel
   float y1m1, y1m2;            // (thread 0 only matters) - unused placeholders
   double peak;                 // running true peak of this thread
   int64_t hop_idx, hop_off;    // hop index / offset of this thread's chunk start
+  int64_t own_from;            // time segments: first sample whose peak this workgroup reports ...
+  int64_t hop_lo, hop_hi;      // ... and the hops [hop_lo, hop_hi) it accumulates (each hop has exactly one owner)
 };
 
-__device__ __forceinline__ void meter_init(MeterState& m, const MeterPlan& pl, int64_t first_sample) {
+// A time segment of a (track, channel) walk: tiles [T0, T1), entered at tile Tw <= T0 with cold state (the warm-up
+// re-run).  A 100 ms hop belongs to the segment that holds its LAST sample, so the owner also sums the part of the
+// hop that lies in its warm-up tiles: every hop sum is accumulated by one workgroup, in tile order - deterministic,
+// no atomics.  (Needs warm >= 2 tiles + the settle time of whatever feeds the meter: a hop is 1.17 tiles.)
+struct Segment {
+  int64_t T0, T1, Tw, own_from, hop_lo, hop_hi;
+};
+__device__ __forceinline__ Segment make_segment(int64_t seg_idx, int64_t seg_tiles, int64_t warm, int64_t ntiles, int64_t hop, int64_t nhops) {
+  Segment g;
+  g.T0 = seg_idx * seg_tiles;
+  g.T1 = g.T0 + seg_tiles; if (g.T1 > ntiles) g.T1 = ntiles;
+  g.Tw = g.T0 - warm > 0 ? g.T0 - warm : 0;
+  g.own_from = g.T0 * kTile;
+  g.hop_lo = hop > 0 ? g.own_from / hop : 0;
+  g.hop_hi = (g.T1 >= ntiles || hop <= 0) ? nhops : (g.T1 * kTile) / hop;
+  if (g.hop_hi > nhops) g.hop_hi = nhops;
+  return g;
+}
+
+__device__ __forceinline__ void meter_init(MeterState& m, const MeterPlan& pl, int64_t first_sample, const Segment* seg = nullptr) {
+  m.own_from = seg ? seg->own_from : 0;
+  m.hop_lo = seg ? seg->hop_lo : 0;
+  m.hop_hi = seg ? seg->hop_hi : pl.nhops;
   biquad_lane_power(pl.shelf, lane_id(), m.P1);
   biquad_lane_power(pl.hp, lane_id(), m.P2);
   m.S1a = m.S1b = m.S2a = m.S2b = 0;
@@ -55,7 +79,7 @@ __device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3],
     for (int k = 0; k < C; k++) {
       const double y3 = x[k];
       const int64_t i = base + k;
-      if (i >= 3 && i < n) pk = fmax(pk, true_peak4(y0, y1, y2, y3));
+      if (i >= 3 && i < n && i >= m.own_from) pk = fmax(pk, true_peak4(y0, y1, y2, y3));
       y0 = y1; y1 = y2; y2 = y3;
     }
     m.peak = pk;
@@ -80,9 +104,11 @@ __device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3],
     const double zz = (base + k < lim) ? z * z : 0.0;
     if (k < to_boundary) sA += zz; else sB += zz;
   }
-  const int64_t h_first = tile_base / pl.hop;
+  int64_t h_first = tile_base / pl.hop;
   int64_t last = tile_base + kTile - 1; if (last > lim - 1) last = lim - 1;
-  const int64_t h_last = last >= tile_base ? last / pl.hop : h_first - 1;
+  int64_t h_last = last >= tile_base ? last / pl.hop : h_first - 1;
+  if (h_first < m.hop_lo) h_first = m.hop_lo;
+  if (h_last > m.hop_hi - 1) h_last = m.hop_hi - 1;
   double* part = lds + 16;
   for (int64_t h0 = h_first; h0 <= h_last; h0 += 4) {
     __syncthreads();
@@ -110,13 +136,17 @@ __device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3],
   while (m.hop_off >= pl.hop) { m.hop_off -= pl.hop; m.hop_idx++; }
 }
 
-// Workgroup-wide final peak -> peaks[0]
+// Workgroup-wide final peak, max-ed into peaks[0] (zeroed before the launch; segments of one channel share it).
+// Non-negative doubles order like their bit patterns.
 __device__ __forceinline__ void meter_finish(MeterState& m, double* lds, double* peak_out) {
   const double w = wave_max(m.peak);
   __syncthreads();
   if (lane_id() == 0) lds[wave_id()] = w;
   __syncthreads();
-  if (threadIdx.x == 0) *peak_out = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+  if (threadIdx.x == 0) {
+    const double pk = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(peak_out), (unsigned long long)__double_as_longlong(pk));
+  }
 }
 
 }  // namespace wam

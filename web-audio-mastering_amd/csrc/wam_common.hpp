@@ -62,6 +62,9 @@ struct Tuning {
   int64_t fx_seg_tiles = 0;       // exciter / warmth / punch: tiles per segment, 0 = pick_segment_tiles()
   int64_t lti_warm_tiles = 2;     // kernels whose only state is LTI filters >= 30 Hz: e^-11 per tile at 30 Hz, e^-75 at 200 Hz
   int64_t punch_warm_tiles = 48;  // slow transient follower, 250 ms release: exp(-196608/12000) = 8e-8
+  int64_t meter_seg_tiles = 0;    // kernels with a fused meter (k_meter, k_gain_meter, k_lim_apply, k_front): 0 = pick_segment_tiles()
+  int64_t meter_warm_tiles = 4;   // a straddling 100 ms hop reaches back 1.17 tiles; K-weighting high-pass e^-20 per tile
+  int64_t glue_warm_tiles = 50;   // glue follower, 250 ms release (+2 for the straddling hop)
 };
 Tuning& tuning();
 
