@@ -27,118 +27,132 @@ struct DeharshPlan {
   uint8_t band_of[kBins];
 };
 
-__device__ __forceinline__ unsigned brev11(unsigned v) { return __brev(v) >> 21; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 
-// forward DIF, natural order in -> bit-reversed order out.  tw[k] = exp(-2 pi i k / N), k < N/2.  256 threads.
-__device__ __forceinline__ void fft_fwd(float2* z, const float2* tw) {
-  const int t = threadIdx.x;
-  for (int m = kN; m >= 8; m >>= 2) {          // fused stages of block size m and m/2
-    const int q = m >> 2, step = kN / m;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int g = t + r * 256;               // 512 groups of 4 points
-      const int j = g % q, b = (g / q) * m;
-      const int p0 = b + j, p1 = p0 + q, p2 = p0 + 2 * q, p3 = p0 + 3 * q;
-      const float2 a = z[p0], bb = z[p1], c = z[p2], d = z[p3];
-      // stage m: (a,c) twiddle W_m^j, (b,d) twiddle W_m^(j+q)
-      float2 s0 = make_float2(a.x + c.x, a.y + c.y), d0 = make_float2(a.x - c.x, a.y - c.y);
-      float2 s1 = make_float2(bb.x + d.x, bb.y + d.y), d1 = make_float2(bb.x - d.x, bb.y - d.y);
-      d0 = cmul(d0, tw[j * step]);
-      d1 = cmul(d1, tw[(j + q) * step]);
-      // stage m/2: (s0,s1) and (d0,d1) twiddle W_(m/2)^j
-      const float2 w2 = tw[j * step * 2];
-      z[p0] = make_float2(s0.x + s1.x, s0.y + s1.y);
-      z[p1] = cmul(make_float2(s0.x - s1.x, s0.y - s1.y), w2);
-      z[p2] = make_float2(d0.x + d1.x, d0.y + d1.y);
-      z[p3] = cmul(make_float2(d0.x - d1.x, d0.y - d1.y), w2);
-    }
-    __syncthreads();
+// ---- the transform ------------------------------------------------------------------------------------
+// A 2048-point real frame is transformed as a 1024-point complex FFT of z[m] = x[2m] + i x[2m+1] plus an O(N)
+// split step (and the mirror image of that for the inverse), which halves the butterfly work and LDS traffic.
+// The 1024-point FFT is a radix-4 Stockham autosort (natural order in and out, no bit reversal): 256 threads, one
+// butterfly per thread and pass, five passes.  Every pass reads z[g + 256 r] (unit stride across lanes) and
+// writes 4 (g - j) + j + r Ls; the array is padded by 4 entries every 16 so that those strided writes spread over
+// the LDS banks.  Tables: twA[k] = exp(-2 pi i k / 1024), k < 768; twB[k] = exp(-2 pi i k / 2048), k <= 512.
+constexpr int kM = 1024, kZ = kM + kM / 4, kTwA = 768, kTwB = 513;
+__device__ __forceinline__ int padz(int i) { return i + ((i >> 4) << 2); }
+
+template <bool INV>
+__device__ __forceinline__ void r4_butterfly(float2 a[4]) {
+  const float2 s02 = make_float2(a[0].x + a[2].x, a[0].y + a[2].y), d02 = make_float2(a[0].x - a[2].x, a[0].y - a[2].y);
+  const float2 s13 = make_float2(a[1].x + a[3].x, a[1].y + a[3].y), d13 = make_float2(a[1].x - a[3].x, a[1].y - a[3].y);
+  a[0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+  a[2] = make_float2(s02.x - s13.x, s02.y - s13.y);
+  if (!INV) {   // W4 = -i
+    a[1] = make_float2(d02.x + d13.y, d02.y - d13.x);
+    a[3] = make_float2(d02.x - d13.y, d02.y + d13.x);
+  } else {
+    a[1] = make_float2(d02.x - d13.y, d02.y + d13.x);
+    a[3] = make_float2(d02.x + d13.y, d02.y - d13.x);
   }
-  // last stage, block size 2 (2048 = 4^5 * 2)
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int p = 2 * (t + r * 256);
-    const float2 a = z[p], b = z[p + 1];
-    z[p] = make_float2(a.x + b.x, a.y + b.y);
-    z[p + 1] = make_float2(a.x - b.x, a.y - b.y);
-  }
-  __syncthreads();
 }
 
-// inverse DIT, bit-reversed order in -> natural order out, unscaled (caller multiplies by 1/N)
-__device__ __forceinline__ void fft_inv(float2* z, const float2* tw) {
-  const int t = threadIdx.x;
+// a[r] = input element g + 256 r (in registers).  Result in z (padded, natural order), visible after the final barrier.
+// Unnormalised in both directions.  The caller guarantees that nobody still reads z when this is entered.
+template <bool INV>
+__device__ __forceinline__ void fft1024(float2 a[4], float2* z, const float2* twA) {
+  const int g = threadIdx.x;
+  r4_butterfly<INV>(a);
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int p = 2 * (t + r * 256);
-    const float2 a = z[p], b = z[p + 1];
-    z[p] = make_float2(a.x + b.x, a.y + b.y);
-    z[p + 1] = make_float2(a.x - b.x, a.y - b.y);
-  }
+  for (int r = 0; r < 4; r++) z[padz(4 * g + r)] = a[r];
   __syncthreads();
-  for (int m = 8; m <= kN; m <<= 2) {          // fused stages of block size m/2 and m
-    const int q = m >> 2, step = kN / m;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int g = t + r * 256;
-      const int j = g % q, b = (g / q) * m;
-      const int p0 = b + j, p1 = p0 + q, p2 = p0 + 2 * q, p3 = p0 + 3 * q;
-      const float2 a = z[p0], bb = z[p1], c = z[p2], d = z[p3];
-      // stage m/2: (a,b) and (c,d) with conj W_(m/2)^j
-      const float2 w2 = tw[j * step * 2];
-      const float2 tb = cmulc(bb, w2), td = cmulc(d, w2);
-      const float2 s0 = make_float2(a.x + tb.x, a.y + tb.y), d0 = make_float2(a.x - tb.x, a.y - tb.y);
-      const float2 s1 = make_float2(c.x + td.x, c.y + td.y), d1 = make_float2(c.x - td.x, c.y - td.y);
-      // stage m: (s0,s1) with conj W_m^j, (d0,d1) with conj W_m^(j+q)
-      const float2 t1 = cmulc(s1, tw[j * step]);
-      const float2 t3 = cmulc(d1, tw[(j + q) * step]);
-      z[p0] = make_float2(s0.x + t1.x, s0.y + t1.y);
-      z[p2] = make_float2(s0.x - t1.x, s0.y - t1.y);
-      z[p1] = make_float2(d0.x + t3.x, d0.y + t3.y);
-      z[p3] = make_float2(d0.x - t3.x, d0.y - t3.y);
+  for (int s = 1; s < 5; s++) {
+    const int Ls = 1 << (2 * s), shift = 8 - 2 * s;
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[r] = z[padz(g + 256 * r)];
+    __syncthreads();
+    const int j = g & (Ls - 1);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+      const float2 w = twA[(r * j) << shift];
+      a[r] = INV ? cmulc(a[r], w) : cmul(a[r], w);
     }
+    r4_butterfly<INV>(a);
+    const int base = ((g - j) << 2) + j;
+#pragma unroll
+    for (int r = 0; r < 4; r++) z[padz(base + r * Ls)] = a[r];
     __syncthreads();
   }
+}
+
+// Split step: from Z = FFT1024(z) to the spectrum X of the real frame for the pair of bins (k, 1024 - k), 1 <= k <= 511.
+//   Xe = (Z[k] + conj Z[M-k]) / 2,  Xo = -i (Z[k] - conj Z[M-k]) / 2,  X[k] = Xe + W^k Xo,  X[M-k] = conj(Xe - W^k Xo)
+struct BinPair { float2 xe, t; };      // X[k] = xe + t, conj(X[M-k]) = xe - t
+__device__ __forceinline__ BinPair split_pair(float2 zk, float2 zm, float2 w) {
+  const float2 bq = make_float2(zm.x, -zm.y);
+  BinPair p;
+  p.xe = make_float2(0.5f * (zk.x + bq.x), 0.5f * (zk.y + bq.y));
+  const float2 d = make_float2(0.5f * (zk.x - bq.x), 0.5f * (zk.y - bq.y));
+  p.t = cmul(make_float2(d.y, -d.x), w);
+  return p;
 }
 
 // Band RMS of every frame.  grid = (frame groups, channels); each workgroup handles frames f = blockIdx.x, += gridDim.x.
 __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                   const float2* __restrict__ twg, const float* __restrict__ wing,
                                                   float* __restrict__ band_rms, double pre_gain) {
-  __shared__ float2 z[kN];
-  __shared__ float2 tw[kN / 2];
+  __shared__ float2 z[kZ];
+  __shared__ float2 tw[kTwA + kTwB];
+  __shared__ float win[kN];
   __shared__ float part[4][kBands];
   const DeharshPlan& P = *dp;
+  const float2* twA = tw; const float2* twB = tw + kTwA;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   const int t = threadIdx.x;
-  for (int i = t; i < kN / 2; i += 256) tw[i] = twg[i];
+  for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
+  for (int i = t; i < kN; i += 256) win[i] = wing[i];
+  // bins of this thread: pairs k1 = t (t = 0: DC, and bin 512 in the second slot) and k2 = t + 256
+  const int k1 = t, k2 = t + 256;
+  const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
+  __syncthreads();
   for (int64_t f = blockIdx.x; f < P.nframes; f += gridDim.x) {
     const int64_t pos = f * kHop;
-    __syncthreads();
+    float2 a[4];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const int i = t + r * 256;
-      float v = x[pos + i];
-      if (pre_gain != 1.0) v = f32r((double)v * pre_gain);
-      if (!(v == v)) v = 0.0f;                                     // (input[i] || 0)
-      z[i] = make_float2(f32r((double)v * (double)wing[i]), 0.0f);   // fft.js:43-45
+    for (int r = 0; r < 4; r++) {
+      const int i = 2 * (t + 256 * r);
+      float v0 = x[pos + i], v1 = x[pos + i + 1];
+      if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
+      if (!(v0 == v0)) v0 = 0.0f;                                  // (input[i] || 0)
+      if (!(v1 == v1)) v1 = 0.0f;
+      a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));   // fft.js:43-45
     }
-    __syncthreads();
-    fft_fwd(z, tw);
+    fft1024<false>(a, z, twA);
+    float m2[4];                                                   // |X|^2 of the four bins (dynamic-processor.js:456-460)
+    {
+      const float2 zk = z[padz(k2)], zm = z[padz(kM - k2)];
+      const BinPair p = split_pair(zk, zm, twB[k2]);
+      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xm = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+      m2[2] = xk.x * xk.x + xk.y * xk.y; m2[3] = xm.x * xm.x + xm.y * xm.y;
+    }
+    if (t == 0) {
+      const float2 z0 = z[padz(0)], zh = z[padz(512)];
+      const float x0 = z0.x + z0.y;
+      m2[0] = x0 * x0; m2[1] = zh.x * zh.x + zh.y * zh.y;
+    } else {
+      const float2 zk = z[padz(k1)], zm = z[padz(kM - k1)];
+      const BinPair p = split_pair(zk, zm, twB[k1]);
+      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xm = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+      m2[0] = xk.x * xk.x + xk.y * xk.y; m2[1] = xm.x * xm.x + xm.y * xm.y;
+    }
     float be[kBands];
 #pragma unroll
     for (int b = 0; b < kBands; b++) be[b] = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int k = t + r * 256;
-      const float2 c = z[brev11(k)];
-      const float mag = sqrtf(c.x * c.x + c.y * c.y);            // dynamic-processor.js:456-460
-      const int bnd = P.band_of[k];
+    for (int q = 0; q < 4; q++) {
+      const float mag = sqrtf(m2[q]);                              // the reference squares the f32 magnitude (:335-337)
 #pragma unroll
-      for (int b = 0; b < kBands; b++) if (b == bnd) be[b] += mag * mag;
+      for (int b = 0; b < kBands; b++) if (b == bnd[q]) be[b] += mag * mag;
     }
 #pragma unroll
     for (int b = 0; b < kBands; b++) {
@@ -153,10 +167,14 @@ __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, 
       const float rms = P.cnt[t] > 0 ? f32r(sqrt((double)s / (double)P.cnt[t])) : s;     // :335-339
       band_rms[(chan * P.nframes + f) * kBands + t] = rms;
     }
+    // the next frame's first write to z / part comes after this frame's reads: fft1024 writes z only after all threads
+    // passed the barrier above, and part is rewritten after the barriers inside fft1024
   }
 }
 
 // Per (channel, band): follower over frames, gain computer.  band_gain_db: [chan][frame][7] float.
+// The recurrence is serial over ~17 k frames; loads are issued 16 frames ahead so that the walk is bound by the
+// arithmetic, not by one memory round trip per frame.
 __global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
                             float* __restrict__ band_gain_db) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,16 +182,27 @@ __global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPla
   const DeharshPlan& P = *dp;
   const int chan = id / kBands, b = id % kBands;
   double env = 0;
-  const double A = P.A[b], R = P.R[b];
-  for (int64_t f = 0; f < P.nframes; f++) {
-    const double a = fabs((double)band_rms[((int64_t)chan * P.nframes + f) * kBands + b]);
-    env = (a > env) ? A * env + (1 - A) * a : R * env + (1 - R) * a;                    // :33-43
-    const double edb = env > 0 ? 20 * log10(env) : -INFINITY;
-    double gdb;
-    if (edb <= P.ks[b]) gdb = 0;                                                         // :75-90
-    else if (edb >= P.ke[b]) { const double ex = edb - P.thr[b]; gdb = ex / P.ratio[b] - ex; }
-    else { const double kp = (edb - P.ks[b]) / P.knee[b]; const double full = (edb - P.thr[b]) * (1 - 1 / P.ratio[b]); gdb = -full * kp * kp; }
-    band_gain_db[((int64_t)chan * P.nframes + f) * kBands + b] = f32r(gdb);
+  const double A = P.A[b], R = P.R[b], ks = P.ks[b], ke = P.ke[b], thr = P.thr[b], ratio = P.ratio[b], knee = P.knee[b];
+  const float* src = band_rms + (int64_t)chan * P.nframes * kBands + b;
+  float* dst = band_gain_db + (int64_t)chan * P.nframes * kBands + b;
+  constexpr int kAhead = 16;
+  for (int64_t f0 = 0; f0 < P.nframes; f0 += kAhead) {
+    float a[kAhead], g[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) a[j] = (f0 + j < P.nframes) ? src[(f0 + j) * kBands] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const double av = fabs((double)a[j]);
+      env = (av > env) ? A * env + (1 - A) * av : R * env + (1 - R) * av;                  // :33-43
+      const double edb = env > 0 ? 20 * log10(env) : -INFINITY;
+      double gdb;
+      if (edb <= ks) gdb = 0;                                                              // :75-90
+      else if (edb >= ke) { const double ex = edb - thr; gdb = ex / ratio - ex; }
+      else { const double kp = (edb - ks) / knee; const double full = (edb - thr) * (1 - 1 / ratio); gdb = -full * kp * kp; }
+      g[j] = f32r(gdb);
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) if (f0 + j < P.nframes) dst[(f0 + j) * kBands] = g[j];
   }
 }
 
@@ -186,19 +215,20 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
                                                   const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
                                                   const float* __restrict__ wing, const float* __restrict__ band_gain_db, double pre_gain,
                                                   int64_t seg_frames, int64_t warm) {
-  __shared__ float2 z[kN];
-  __shared__ float2 tw[kN / 2];
+  __shared__ float2 z[kZ];
+  __shared__ float2 tw[kTwA + kTwB];
   __shared__ float win[kN];
   __shared__ float xin[kN];      // input ring: sample s at xin[s & 2047]
   __shared__ float ola[kN];      // overlap-add ring
   __shared__ float bg[kBands];
   const DeharshPlan& P = *dp;
+  const float2* twA = tw; const float2* twB = tw + kTwA;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
   const int t = threadIdx.x;
   const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423
-  for (int i = t; i < kN / 2; i += 256) tw[i] = twg[i];
+  for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
   for (int i = t; i < kN; i += 256) { win[i] = wing[i]; ola[i] = 0.0f; }
   auto load_in = [&](int64_t s) -> float {
     float v = (s < n) ? x[s] : 0.0f;
@@ -211,6 +241,10 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
   const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
   const bool last_seg = f1 >= F;
   if (F > 0) for (int i = t; i < kN - kHop; i += 256) { const int64_t s = fs * kHop + i; xin[s & (kN - 1)] = load_in(s); }   // each frame adds 512
+  // bins of this thread: the pairs (k1, 1024 - k1) and (k2, 1024 - k2), k1 = t, k2 = t + 256; thread 0 holds DC and, in
+  // the slot of "1024 - 0", bin 512.  avg[] = the resonance detector's running mean of those four bins.
+  const int k1 = t, k2 = t + 256;
+  const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
   float avg[4] = {0, 0, 0, 0};
   for (int64_t f = fs; f < f1; f++) {
     const int64_t pos = f * kHop;
@@ -220,48 +254,78 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
     for (int i = t; i < kHop; i += 256) { const int64_t s = pos + (kN - kHop) + i; xin[s & (kN - 1)] = load_in(s); }
     if (t < kBands) bg[t] = band_gain_db[(chan * F + f) * kBands + t];
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const int i = t + r * 256;
-      float v = xin[(pos + i) & (kN - 1)];
-      if (!(v == v)) v = 0.0f;
-      z[i] = make_float2(f32r((double)v * (double)win[i]), 0.0f);
-    }
-    __syncthreads();
-    fft_fwd(z, tw);
-    // gains per bin (dynamic-processor.js:354-382), resonance detector (:194-233)
+    float2 a[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int k = t + r * 256;
-      const unsigned p = brev11(k);
-      const float2 c = z[p];
-      const float mag = sqrtf(c.x * c.x + c.y * c.y);
+      const int i = 2 * (t + 256 * r);
+      const int o = (int)((pos + i) & (kN - 1));               // pos is even: o + 1 does not wrap
+      float v0 = xin[o], v1 = xin[o + 1];
+      if (!(v0 == v0)) v0 = 0.0f;
+      if (!(v1 == v1)) v1 = 0.0f;
+      a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));
+    }
+    fft1024<false>(a, z, twA);
+    // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
+    const bool first = f == fs;            // the detector's first frame (:203-207); a warm start for later segments
+    auto bin_gain = [&](float mag, float& av_state, int band) -> float {
       float res = 0.0f;
-      if (f == fs) avg[r] = mag;            // the detector's first frame (:203-207); a warm start for later segments
+      if (first) av_state = mag;
       else {
-        avg[r] = f32r(0.3 * (double)mag + (1 - 0.3) * (double)avg[r]);
-        const double av = avg[r];
+        av_state = f32r(0.3 * (double)mag + (1 - 0.3) * (double)av_state);
+        const double av = av_state;
         if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, ((double)mag / av - 1.5) / 2));
       }
+      double gdb = bg[band];
+      if (res > 0) gdb += -3.0 * (double)res * 0.2;
+      return exp2f((float)(gdb * 0.16609640474436813));        // 10^(gdb/20), stored as f32 by the reference
+    };
+    // scale the bins (mirror implied, :471-476) and fold the spectrum back into the 1024-point input of the inverse:
+    //   Ye = (Y[k] + conj Y[M-k]) / 2, Yo = (Y[k] - conj Y[M-k]) / 2 conj(W^k), Z'[k] = Ye + i Yo, Z'[M-k] = conj Ye + i conj Yo
+    auto do_pair = [&](int k, float& av_k, float& av_m, int band_k, int band_m) {
+      const float2 zk = z[padz(k)], zm = z[padz(kM - k)];
+      const float2 w = twB[k];
+      const BinPair p = split_pair(zk, zm, w);
+      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xmc = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+      const float gk = bin_gain(sqrtf(xk.x * xk.x + xk.y * xk.y), av_k, band_k);
+      const float gm = bin_gain(sqrtf(xmc.x * xmc.x + xmc.y * xmc.y), av_m, band_m);
+      if (!synth) return;
+      const float2 yk = make_float2(xk.x * gk, xk.y * gk), ymc = make_float2(xmc.x * gm, xmc.y * gm);
+      const float2 ye = make_float2(0.5f * (yk.x + ymc.x), 0.5f * (yk.y + ymc.y));
+      const float2 yo = cmulc(make_float2(0.5f * (yk.x - ymc.x), 0.5f * (yk.y - ymc.y)), w);
+      z[padz(k)] = make_float2(ye.x - yo.y, ye.y + yo.x);
+      z[padz(kM - k)] = make_float2(ye.x + yo.y, yo.x - ye.y);
+    };
+    do_pair(k2, avg[2], avg[3], bnd[2], bnd[3]);
+    if (t == 0) {
+      const float2 z0 = z[padz(0)], zh = z[padz(512)];
+      const float x0 = z0.x + z0.y, xny = z0.x - z0.y;          // X[0] and X[1024] are real; the Nyquist bin is not scaled
+      const float g0 = bin_gain(fabsf(x0), avg[0], bnd[0]);
+      const float gh = bin_gain(sqrtf(zh.x * zh.x + zh.y * zh.y), avg[1], bnd[1]);
       if (synth) {
-        double gdb = bg[P.band_of[k]];
-        if (res > 0) gdb += -3.0 * (double)res * 0.2;
-        const float g = exp2f((float)(gdb * 0.16609640474436813));      // 10^(gdb/20), stored as f32 by the reference
-        const float2 s = make_float2(c.x * g, c.y * g);
-        z[p] = s;
-        if (k > 0) z[brev11(kN - k)] = make_float2(s.x, -s.y);          // mirror, :471-476
+        const float y0 = x0 * g0;
+        z[padz(0)] = make_float2(0.5f * (y0 + xny), 0.5f * (y0 - xny));
+        z[padz(512)] = make_float2(zh.x * gh, zh.y * gh);
       }
+    } else {
+      do_pair(k1, avg[0], avg[1], bnd[0], bnd[1]);
     }
     if (!synth) continue;                   // uniform across the workgroup
     __syncthreads();
-    fft_inv(z, tw);
-    // synthesis window + overlap-add (fft.js:63-65, dynamic-processor.js:483-487)
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const int i = t + r * 256;
-      const float pr = f32r((double)(z[i].x * (1.0f / kN)) * (double)win[i]);
+    for (int r = 0; r < 4; r++) a[r] = z[padz(t + 256 * r)];
+    __syncthreads();
+    fft1024<true>(a, z, twA);
+    // synthesis window + overlap-add (fft.js:63-65, dynamic-processor.js:483-487): z[m] = 1024 (y[2m], y[2m+1])
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = t + 256 * r, i = 2 * m;
+      const float2 zz = z[padz(m)];
+      const float pr0 = f32r((double)(zz.x * (1.0f / kM)) * (double)win[i]);
+      const float pr1 = f32r((double)(zz.y * (1.0f / kM)) * (double)win[i + 1]);
       const int64_t s = pos + i;
-      if (s < n) { const int o = (int)(s & (kN - 1)); ola[o] = f32r((double)ola[o] + (double)pr); }
+      const int o = (int)(s & (kN - 1));
+      if (s < n) ola[o] = f32r((double)ola[o] + (double)pr0);
+      if (s + 1 < n) ola[o + 1] = f32r((double)ola[o + 1] + (double)pr1);
     }
     __syncthreads();
     // samples [pos, pos + 512) are complete: normalise by 4, mix, emit, and free the ring slots
@@ -317,13 +381,14 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   DevBuf plan, twb, winb, rms, gdb;
   int rc;
   rc = plan.alloc(sizeof(dp)); if (rc) return rc;
-  rc = twb.alloc(sizeof(float2) * (kN / 2)); if (rc) return rc;
+  rc = twb.alloc(sizeof(float2) * (kTwA + kTwB)); if (rc) return rc;
   rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
-  std::vector<float2> tw(kN / 2);
+  std::vector<float2> tw(kTwA + kTwB);
   std::vector<float> win(kN);
-  for (int k = 0; k < kN / 2; k++) { const double a = -2 * M_PI * k / kN; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  for (int k = 0; k < kTwA; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  for (int k = 0; k < kTwB; k++) { const double a = -2 * M_PI * k / kN; tw[kTwA + k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int i = 0; i < kN; i++) win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / (kN - 1))));     // utils.js:98-104
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
