@@ -36,6 +36,11 @@ int wam_profile_read(char* buf, size_t cap);
  * fixtures cross segment seams, and for tuning runs. */
 int wam_tune(const char* key, int64_t value);
 
+/* The library keeps the device memory of its intermediates (per device, grow-only, reused by later calls) because a
+ * 256-track render group needs tens of GB and allocating that per call costs more than the kernels.  This call returns
+ * all idle blocks to the driver. */
+int wam_trim_workspace(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,47 @@ void set_error(const char* fmt, ...) {
 
 Tuning& tuning() { static Tuning t; return t; }
 
+// ---- workspace pool -----------------------------------------------------------
+struct PoolBlock { void* p; size_t bytes; int device; };
+static std::mutex g_pool_mu;
+static std::vector<PoolBlock> g_pool;                 // idle blocks
+
+void* pool_alloc(size_t bytes, size_t* granted) {
+  const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(2) << 20) : 256;
+  const size_t want = (bytes + gran - 1) / gran * gran;
+  int dev = 0; (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); i++) {
+      const PoolBlock& b = g_pool[i];
+      if (b.device != dev || b.bytes < want || b.bytes > want + want / 4 + 4096) continue;      // best fit, at most 25 % slack
+      if (best < 0 || b.bytes < g_pool[best].bytes) best = i;
+    }
+    if (best >= 0) {
+      void* p = g_pool[best].p; *granted = g_pool[best].bytes;
+      g_pool.erase(g_pool.begin() + best);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {                              // give the idle blocks back and try once more
+    (void)hipGetLastError();
+    wam_trim_workspace();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
+  *granted = want;
+  return p;
+}
+void pool_free(void* p, size_t granted) {
+  if (!p) return;
+  int dev = 0; (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back(PoolBlock{p, granted, dev});
+}
+
 // ---- per-kernel timing ------------------------------------------------------
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 static bool g_prof_on = false;
@@ -103,6 +144,14 @@ extern "C" {
 const char* wam_last_error(void) { return g_err.c_str(); }
 const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
 
+int wam_trim_workspace(void) {
+  std::vector<wam::PoolBlock> blocks;
+  { std::lock_guard<std::mutex> lk(wam::g_pool_mu); blocks.swap(wam::g_pool); }
+  int cur = 0; (void)hipGetDevice(&cur);
+  for (const auto& b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+  (void)hipSetDevice(cur);
+  return WAM_OK;
+}
 int wam_tune(const char* key, int64_t value) {
   if (!key || value < 0) { wam::set_error("wam_tune: bad argument"); return WAM_ERR_INVALID; }
   wam::Tuning& t = wam::tuning();

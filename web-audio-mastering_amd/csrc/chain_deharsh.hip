@@ -172,37 +172,43 @@ __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, 
   }
 }
 
-// Per (channel, band): follower over frames, gain computer.  band_gain_db: [chan][frame][7] float.
-// The recurrence is serial over ~17 k frames; loads are issued 16 frames ahead so that the walk is bound by the
-// arithmetic, not by one memory round trip per frame.
+// GainComputer.computeGainDb, dynamic-processor.js:75-90, on the follower's envelope; the reference keeps the result in a Float32Array
+__device__ __forceinline__ float band_gain_db_of(double env, const DeharshPlan& P, int b) {
+  const double edb = env > 0 ? 20 * log10(env) : -INFINITY;
+  double gdb;
+  if (edb <= P.ks[b]) gdb = 0;
+  else if (edb >= P.ke[b]) { const double ex = edb - P.thr[b]; gdb = ex / P.ratio[b] - ex; }
+  else { const double kp = (edb - P.ks[b]) / P.knee[b]; const double full = (edb - P.thr[b]) * (1 - 1 / P.ratio[b]); gdb = -full * kp * kp; }
+  return f32r(gdb);
+}
+
+// Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43).  band_env: [chan][frame][7]
+// double.  The recurrence is serial over ~17 k frames (its release coefficient is per SAMPLE but it is stepped per
+// frame, so its memory spans the whole track: no warm-up segmentation); only the recurrence runs here - the
+// logarithm and the knee are evaluated by the consumer - and loads are issued 16 frames ahead.
 __global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
-                            float* __restrict__ band_gain_db) {
+                            double* __restrict__ band_env) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchan * kBands) return;
   const DeharshPlan& P = *dp;
   const int chan = id / kBands, b = id % kBands;
   double env = 0;
-  const double A = P.A[b], R = P.R[b], ks = P.ks[b], ke = P.ke[b], thr = P.thr[b], ratio = P.ratio[b], knee = P.knee[b];
+  const double A = P.A[b], R = P.R[b];
   const float* src = band_rms + (int64_t)chan * P.nframes * kBands + b;
-  float* dst = band_gain_db + (int64_t)chan * P.nframes * kBands + b;
+  double* dst = band_env + (int64_t)chan * P.nframes * kBands + b;
   constexpr int kAhead = 16;
   for (int64_t f0 = 0; f0 < P.nframes; f0 += kAhead) {
-    float a[kAhead], g[kAhead];
+    float a[kAhead]; double e[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; j++) a[j] = (f0 + j < P.nframes) ? src[(f0 + j) * kBands] : 0.0f;
 #pragma unroll
     for (int j = 0; j < kAhead; j++) {
       const double av = fabs((double)a[j]);
-      env = (av > env) ? A * env + (1 - A) * av : R * env + (1 - R) * av;                  // :33-43
-      const double edb = env > 0 ? 20 * log10(env) : -INFINITY;
-      double gdb;
-      if (edb <= ks) gdb = 0;                                                              // :75-90
-      else if (edb >= ke) { const double ex = edb - thr; gdb = ex / ratio - ex; }
-      else { const double kp = (edb - ks) / knee; const double full = (edb - thr) * (1 - 1 / ratio); gdb = -full * kp * kp; }
-      g[j] = f32r(gdb);
+      env = (av > env) ? A * env + (1 - A) * av : R * env + (1 - R) * av;
+      e[j] = env;
     }
 #pragma unroll
-    for (int j = 0; j < kAhead; j++) if (f0 + j < P.nframes) dst[(f0 + j) * kBands] = g[j];
+    for (int j = 0; j < kAhead; j++) if (f0 + j < P.nframes) dst[(f0 + j) * kBands] = e[j];
   }
 }
 
@@ -213,7 +219,7 @@ __global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPla
 // more than three before f0 skip the inverse transform.
 __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                   const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
-                                                  const float* __restrict__ wing, const float* __restrict__ band_gain_db, double pre_gain,
+                                                  const float* __restrict__ wing, const double* __restrict__ band_env, double pre_gain,
                                                   int64_t seg_frames, int64_t warm) {
   __shared__ float2 z[kZ];
   __shared__ float2 tw[kTwA + kTwB];
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
     __syncthreads();
     // newest 512 samples of this frame: [pos + 1536, pos + 2048)
     for (int i = t; i < kHop; i += 256) { const int64_t s = pos + (kN - kHop) + i; xin[s & (kN - 1)] = load_in(s); }
-    if (t < kBands) bg[t] = band_gain_db[(chan * F + f) * kBands + t];
+    if (t < kBands) bg[t] = band_gain_db_of(band_env[(chan * F + f) * kBands + t], P, t);
     __syncthreads();
     float2 a[4];
 #pragma unroll
@@ -384,7 +390,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   rc = twb.alloc(sizeof(float2) * (kTwA + kTwB)); if (rc) return rc;
   rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
-  rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
+  rc = gdb.alloc(sizeof(double) * nf * kBands * nchan); if (rc) return rc;
   std::vector<float2> tw(kTwA + kTwB);
   std::vector<float> win(kN);
   for (int k = 0; k < kTwA; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
@@ -398,12 +404,12 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)((nchan * kBands + 63) / 64)), dim3(64), s, (const float*)rms.as<float>(),
-               plan.as<DeharshPlan>(), nchan, gdb.as<float>());
+               plan.as<DeharshPlan>(), nchan, gdb.as<double>());
   }
   const int64_t seg = tuning().dh_seg_frames, warm = tuning().dh_warm_frames;
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
   WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)nseg, (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
-             winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, warm);
+             winb.as<float>(), (const double*)gdb.as<double>(), pre_gain, seg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return
   return WAM_OK;
 }

@@ -22,19 +22,26 @@ int ensure_device();                       // 0 or WAM_ERR_NO_DEVICE; binds the 
     }                                                                                          \
   } while (0)
 
+// Workspace pool (api.hip): device blocks are kept per device after use and handed out again, because a render group
+// needs tens of GB of intermediates and hipMalloc / hipFree of that size costs more than the kernels that use it.
+// Every entry point synchronises its stream before its DevBufs go out of scope, so a block is idle when it returns
+// to the pool.  wam_trim_workspace() (include/wam_synth.h) gives the memory back to the driver.
+void* pool_alloc(size_t bytes, size_t* granted);
+void pool_free(void* p, size_t granted);
+
 // RAII device buffer
 struct DevBuf {
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0, granted = 0;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) pool_free(p, granted); }
   int alloc(size_t nbytes) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { pool_free(p, granted); p = nullptr; }
     bytes = nbytes;
-    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 16);
-    if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e)); return WAM_ERR_NOMEM; }
+    p = pool_alloc(nbytes ? nbytes : 16, &granted);
+    if (!p) return WAM_ERR_NOMEM;          // pool_alloc set the message
     return WAM_OK;
   }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
