@@ -6,7 +6,7 @@
 A step = one pass of the hot path over one batch of synthetic 3-min stereo 48 kHz
 tracks already resident in HBM: the full export chain + LUFS/true-peak metering
 (`--workload chain`, BASELINE.json configs[2] sharded track-wise: `--tracks-per-gpu`
-tracks on each GPU, 128 x 8 GPUs = the 1,024-track batch) or metering only
+tracks on each GPU; the default, 1,024, is the whole configs[2] batch on one GPU) or metering only
 (`--workload meter`, configs[0]).  Tracks are independent, so ranks never exchange
 audio: weak scaling, no data-path collective; torch.distributed is
 used only for the barrier and the max-over-ranks reduction of the step time.
@@ -49,7 +49,8 @@ KERNEL_BYTES = {
     "k_dh_apply": 8,       # read x, write y
     "k_exciter": 8,
     "k_win_peak": 4,
-    "k_warm_punch": 8,
+    "k_warm": 8,
+    "k_punch": 8,
     "k_front": 8,
     "k_sc_env": 6,         # read x (4), write the shared gain envelope (4 per frame = 2 per sample-channel)
     "k_sc_apply": 10,      # read x + envelope, write y
@@ -83,6 +84,32 @@ def profile_read():
     return out
 
 
+GROUP = 256      # tracks per render group inside the library (csrc/chain_api.hip): one launch of a chain kernel covers a group
+
+
+def pmc_traffic(kernel, tracks_per_launch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_summary.csv: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH_SIZE doubled per the gfx950 correction)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    meta = [r for r in rows if r["kernel"] == "#tracks_per_launch"]
+    ref_tracks = float(meta[0]["launches"]) if meta else None
+    for r in rows:
+        if r["kernel"] == kernel:
+            try:
+                b = (float(r["fetch_GB_per_launch_x2"]) + float(r["write_GB_per_launch"])) * 1e9
+            except ValueError:
+                return None
+            if ref_tracks and ref_tracks != tracks_per_launch:
+                b *= tracks_per_launch / ref_tracks          # traffic is proportional to the tracks a launch covers
+            return b
+    return None
+
+
 def cpu_baseline(workload):
     """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload."""
     import oracle_lib as O
@@ -104,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tracks-per-gpu", type=int, default=128)
+    ap.add_argument("--tracks-per-gpu", type=int, default=1024)
     ap.add_argument("--workload", choices=["chain", "meter"], default="chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -167,12 +194,15 @@ def main():
             launches_per_step = cnt / args.steps
             avg_ms = total_ms / cnt
             bpsc = KERNEL_BYTES.get(name)
+            tracks_per_launch = min(T, GROUP) if args.workload == "chain" else T
             if bpsc is not None:
-                alg_bytes = bpsc * T * NCH * N / max(1.0, launches_per_step) if launches_per_step >= 1 else bpsc * T * NCH * N
+                alg_bytes = bpsc * tracks_per_launch * NCH * N
                 achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                            "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                            "algorithmic_bytes_per_launch": alg_bytes}
+                            "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch), "avg_launch_ms": avg_ms,
+                            "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
+                            "note": "the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,400 VALU "
+                                    "lane-instructions per 16 algorithmic bytes against a machine balance of ~5 per byte"}
             else:
                 roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                             "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}

@@ -4,7 +4,7 @@
 set -e
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_$TAG
+OUT=$R/gpurun_out/$TAG/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq -o sq --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/sq.log 2>&1
