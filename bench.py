@@ -66,9 +66,9 @@ class SynthOpts(C.Structure):
                 ("quiet2_from", C.c_int64), ("quiet2_to", C.c_int64), ("quiet2_gain", C.c_double)]
 
 
-def synth_dev(t, ntracks, idx0, opts, amp_step=0.0):
+def synth_dev(t, ntracks, idx0, opts, amp_step=0.0, sr=SR):
     o = SynthOpts(opts.get("amp", 1.0), opts.get("dc", 0.0), opts.get("clickAmp", 0.0), -1, -1, 0.0, -1, -1, 0.0)
-    rc = wam.lib().wam_synth_dev(C.c_void_p(t.data_ptr()), C.c_int(ntracks), C.c_int(NCH), C.c_int64(t.shape[-1]), C.c_double(SR),
+    rc = wam.lib().wam_synth_dev(C.c_void_p(t.data_ptr()), C.c_int(ntracks), C.c_int(NCH), C.c_int64(t.shape[-1]), C.c_double(sr),
                                  C.c_int(idx0), C.byref(o), C.c_double(amp_step), C.c_void_p(0))
     if rc:
         raise wam.WamError(wam.lib().wam_last_error().decode())
@@ -110,20 +110,23 @@ def pmc_traffic(kernel, tracks_per_launch):
     return None
 
 
-def cpu_baseline(workload):
+def cpu_baseline(workload, sr=SR):
     """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload."""
     import oracle_lib as O
-    secs = 20 if workload == "chain" else 60
-    x = O.synth(0, NCH, secs * SR, SR, SYNTH)
+    chain = workload in ("chain", "single", "longform")
+    secs = 20 if chain else (30 if workload == "stft" else 60)
+    x = O.synth(0, NCH, secs * sr, sr, SYNTH)
     t0 = time.perf_counter()
-    if workload == "chain":
-        O.render_chain(x, SR, C2_SETTINGS, "export")
+    if chain:
+        O.render_chain(x, sr, C2_SETTINGS, "export")
+    elif workload == "stft":
+        O.stft_db(x, sr, 4096, 1024)
     else:
-        O.measure_lufs(x, SR)
+        O.measure_lufs(x, sr)
         O.true_peak_db(x)
     dt = time.perf_counter() - t0
     return {"value": secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port",
-            "sample": f"1 track x {secs} s stereo 48 kHz, same synthetic generator and settings, oracle/wam_oracle.c (C restatement of the reference JS), {dt:.1f} s wall"}
+            "sample": f"1 track x {secs} s stereo {sr // 1000} kHz, same synthetic generator and settings, oracle/wam_oracle.c (C restatement of the reference JS), {dt:.1f} s wall"}
 
 
 def main():
@@ -131,8 +134,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tracks-per-gpu", type=int, default=1024)
-    ap.add_argument("--workload", choices=["chain", "meter"], default="chain")
+    ap.add_argument("--tracks-per-gpu", type=int, default=None, help="default 1024 (chain, meter, stft), 1 (single, longform)")
+    ap.add_argument("--workload", choices=["chain", "meter", "single", "longform", "stft"], default="chain",
+                    help="chain: configs[2] (default, the bench line); meter: configs[0] batched; single: configs[1], one 3-min track; "
+                         "longform: configs[3], one 60-min 96 kHz track; stft: configs[4], 4096-point STFT hop 1024 over the corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -149,15 +154,29 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     wam.init(dev.index)
 
-    T = args.tracks_per_gpu
+    global SR, SECONDS, N
+    wl = args.workload
+    chain_like = wl in ("chain", "single", "longform")
+    if wl == "longform":
+        SR, SECONDS = 96000, 3600
+    N = SR * SECONDS
+    T = args.tracks_per_gpu if args.tracks_per_gpu else (1 if wl in ("single", "longform") else 1024)
     x = torch.empty((T, NCH, N), dtype=torch.float32, device=dev)
-    synth_dev(x, T, rank * T, SYNTH, amp_step=0.3 / max(T, 1))      # distinct seed per track, levels 1.6 .. 1.9
-    y = torch.empty_like(x) if args.workload == "chain" else None
+    synth_dev(x, T, rank * T, SYNTH, amp_step=0.3 / max(T, 1), sr=SR)      # distinct seed per track, levels 1.6 .. 1.9
+    y = torch.empty_like(x) if chain_like else None
+    NFFT, HOP = 4096, 1024
+    if wl == "stft":
+        nframes = (N - NFFT) // HOP + 1
+        spec = torch.empty((T, nframes, NFFT // 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        if args.workload == "chain":
+        if chain_like:
             return wam.batch_render_dev(x.data_ptr(), y.data_ptr(), T, NCH, N, SR, C2_SETTINGS, "export")
+        if wl == "stft":
+            wam._check(wam.lib().wam_batch_stft_db_dev(C.c_void_p(x.data_ptr()), C.c_int(T), C.c_int(NCH), C.c_int64(N), C.c_double(SR), C.c_int(NFFT),
+                                                       C.c_int(HOP), C.c_void_p(spec.data_ptr()), C.c_void_p(0), C.c_void_p(0)))
+            return None
         return wam.batch_meter_dev(x.data_ptr(), T, NCH, N, SR)
 
     def barrier():
@@ -177,8 +196,10 @@ def main():
     wam.lib().wam_profile_enable(0)
     dt = wam_dist.max_over_ranks(dt, dev)
     # per-track scalars of every shard, in global track order (the only data that leaves a rank)
-    if args.workload == "chain":
+    if chain_like:
         local = [[r.lufs, r.true_peak_db, r.lufs_in, r.gain_db] for r in res]
+    elif wl == "stft":
+        local = [[float(spec[t].max()), float(spec[t, :, 1:].float().mean())] for t in range(min(T, 4))] + [[0.0, 0.0]] * max(0, T - 4)
     else:
         local = [[float(a), float(b)] for a, b in zip(res[0], res[1])]
     table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64), world * T, dev)
@@ -194,7 +215,9 @@ def main():
             launches_per_step = cnt / args.steps
             avg_ms = total_ms / cnt
             bpsc = KERNEL_BYTES.get(name)
-            tracks_per_launch = min(T, GROUP) if args.workload == "chain" else T
+            tracks_per_launch = min(T, GROUP) if chain_like else T
+            if name == "k_stft":
+                bpsc = 12 / NCH                     # 12 B per MONO sample: 4 read (both channels: 8) ... stated per sample-channel
             if bpsc is not None:
                 alg_bytes = bpsc * tracks_per_launch * NCH * N
                 achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -208,19 +231,24 @@ def main():
                             "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         kernel_ms_per_step = sum(v[1] for v in prof.values()) / args.steps
-        chain_bytes = (16 if args.workload == "chain" else 4) * T * NCH * N
+        chain_bytes = (16 if chain_like else (6 if wl == "stft" else 4)) * T * NCH * N
         out = {
-            "metric": "x realtime (audio-s/s) full master chain+LUFS" if args.workload == "chain" else "x realtime (audio-s/s) LUFS+true-peak meter",
+            "metric": ("x realtime (audio-s/s) full master chain+LUFS" if chain_like else
+                       "x realtime (audio-s/s) 4096-pt STFT hop 1024" if wl == "stft" else "x realtime (audio-s/s) LUFS+true-peak meter"),
             "value": audio_s / dt, "unit": "x realtime (audio-s/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[2] shard: {T} tracks/GPU x 3-min stereo 48 kHz, full export chain "
+            "config": {"workload": ({"chain": f"BASELINE configs[2]: {T} tracks/GPU", "single": "BASELINE configs[1]: one track",
+                                     "longform": "BASELINE configs[3]: one long-form track"}[wl] +
+                                    f" x {SECONDS // 60}-min stereo {SR // 1000} kHz, full export chain "
                                     "(input gain, de-harsh, exciter, tape warmth, punch, 30 Hz HPF + 18 kHz LPF, 5-band EQ 'aifix', glue comp, "
                                     "mono-bass M/S, -14 LUFS normalise, soft clip, TP limiter) + LUFS/true-peak of the result"
-                                    if args.workload == "chain" else
+                                    if chain_like else
+                                    f"BASELINE configs[4]: {T} tracks/GPU x 3-min stereo 48 kHz, 4096-point periodic-Hann STFT, hop 1024, of the mono mix, dB per bin"
+                                    if wl == "stft" else
                                     f"BASELINE configs[0] batched: {T} tracks/GPU x 3-min stereo 48 kHz, integrated LUFS + true peak"),
                        "tracks_per_gpu": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
-                       "settings": C2_SETTINGS if args.workload == "chain" else None, "parallelism": f"track-sharded x{world}, no collective"},
+                       "settings": C2_SETTINGS if chain_like else None, "parallelism": f"track-sharded x{world}, no collective"},
             "roofline": roofline,
             "chain_hbm_frac": (chain_bytes / (kernel_ms_per_step * 1e-3) / 8e12) if kernel_ms_per_step > 0 else None,
             "kernel_ms_per_step": kernel_ms_per_step,
@@ -229,10 +257,10 @@ def main():
         tb = table.cpu()
         out["sample_result"] = {"lufs": float(tb[0, 0]), "true_peak_db": float(tb[0, 1]), "tracks_reported": int(tb.shape[0]),
                                 "lufs_min": float(tb[:, 0].min()), "lufs_max": float(tb[:, 0].max()), "true_peak_db_max": float(tb[:, 1].max())}
-        if args.workload == "chain":
+        if chain_like:
             out["sample_result"].update(lufs_in=float(tb[0, 2]), gain_db=float(tb[0, 3]))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(wl, SR)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -183,6 +183,10 @@ int wam_wav_header(int nch, int64_t n, int sample_rate, int bits, uint8_t out44[
 int wam_stft_db(const float* const* ch, int nch, int64_t n, double sample_rate, int nfft, int hop,
                 float* out_db, float* columns);
 int64_t wam_stft_num_frames(int64_t n, int nfft, int hop);
+/* Device-resident batch (BASELINE.json configs[4]: the corpus through the same per-frame transform):
+ * in_dev [ntracks][nch][n], out_db_dev [ntracks][nframes][nfft/2], columns_dev [ntracks][nframes][256] or NULL. */
+int wam_batch_stft_db_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate, int nfft, int hop,
+                          float* out_db_dev, float* columns_dev, void* stream);
 
 #ifdef __cplusplus
 }

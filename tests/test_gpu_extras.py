@@ -79,3 +79,21 @@ def test_normalize_message(amp, target, ceiling):
             assert a == b
         else:
             assert abs(a - b) <= 0.01
+
+
+def test_batch_stft_dev_matches_single():
+    """configs[4] entry point: device-resident batch == per-track host call (same kernel, track dimension added)."""
+    import ctypes as C
+    import torch
+    sr, n, T = 48000, 20000, 3
+    tracks = [O.synth(60 + t, 2, n, sr, {"amp": 0.8}) for t in range(T)]
+    x = torch.tensor(np.stack([np.stack(t) for t in tracks]), device="cuda")
+    nfr = (n - 4096) // 1024 + 1
+    out = torch.empty((T, nfr, 2048), dtype=torch.float32, device="cuda")
+    cols = torch.empty((T, nfr, 256), dtype=torch.float32, device="cuda")
+    wam._check(wam.lib().wam_batch_stft_db_dev(C.c_void_p(x.data_ptr()), C.c_int(T), C.c_int(2), C.c_int64(n), C.c_double(sr), C.c_int(4096), C.c_int(1024),
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(cols.data_ptr()), C.c_void_p(0)))
+    for t in range(T):
+        ref, rcols = O.stft_db(tracks[t], sr, 4096, 1024, columns=True)
+        assert np.max(np.abs(out[t].cpu().numpy() - ref)) <= 2e-5          # dB; same bar as test_stft
+        assert np.max(np.abs(cols[t].cpu().numpy() - rcols)) <= 2e-5

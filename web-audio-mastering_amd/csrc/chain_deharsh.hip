@@ -183,32 +183,34 @@ __device__ __forceinline__ float band_gain_db_of(double env, const DeharshPlan& 
 }
 
 // Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43).  band_env: [chan][frame][7]
-// double.  The recurrence is serial over ~17 k frames (its release coefficient is per SAMPLE but it is stepped per
-// frame, so its memory spans the whole track: no warm-up segmentation); only the recurrence runs here - the
-// logarithm and the knee are evaluated by the consumer - and loads are issued 16 frames ahead.
-__global__ void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
-                            double* __restrict__ band_env) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= nchan * kBands) return;
+// double.  The release coefficient is per SAMPLE but the follower is stepped per frame, so its memory spans the whole
+// track (no warm-up segmentation); instead one workgroup per (channel, band) walks the frames in tiles of 4,096 with
+// the same policy-iteration scan as the per-sample followers (an hour at 96 kHz is 337 k frames = 83 tiles).  Only
+// the recurrence runs here - the logarithm and the knee are evaluated by the consumer.
+__global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
+                                                        double* __restrict__ band_env) {
+  __shared__ double lds_scan[kSlotDoubles];
   const DeharshPlan& P = *dp;
-  const int chan = id / kBands, b = id % kBands;
-  double env = 0;
+  const int chan = blockIdx.x / kBands, b = blockIdx.x % kBands;
   const double A = P.A[b], R = P.R[b];
-  const float* src = band_rms + (int64_t)chan * P.nframes * kBands + b;
-  double* dst = band_env + (int64_t)chan * P.nframes * kBands + b;
-  constexpr int kAhead = 16;
-  for (int64_t f0 = 0; f0 < P.nframes; f0 += kAhead) {
-    float a[kAhead]; double e[kAhead];
+  const int64_t F = P.nframes;
+  const float* src = band_rms + (int64_t)chan * F * kBands + b;
+  double* dst = band_env + (int64_t)chan * F * kBands + b;
+  LdsSlots slots(lds_scan);
+  double Senv = 0;
+  const int64_t ntiles = (F + kTile - 1) / kTile;
+  for (int64_t t = 0; t < ntiles; t++) {
+    const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
+    float a[C];
 #pragma unroll
-    for (int j = 0; j < kAhead; j++) a[j] = (f0 + j < P.nframes) ? src[(f0 + j) * kBands] : 0.0f;
+    for (int k = 0; k < C; k++) a[k] = (base + k < F) ? fabsf(src[(base + k) * kBands]) : 0.0f;
+    // frames past the end: a = 0 keeps the recurrence defined; nothing is stored for them
+    double e = follower_solve(a, A, R, Senv, slots.next());
 #pragma unroll
-    for (int j = 0; j < kAhead; j++) {
-      const double av = fabs((double)a[j]);
-      env = (av > env) ? A * env + (1 - A) * av : R * env + (1 - R) * av;
-      e[j] = env;
+    for (int k = 0; k < C; k++) {
+      e = follower_step(e, (double)a[k], A, R);
+      if (base + k < F) dst[(base + k) * kBands] = e;
     }
-#pragma unroll
-    for (int j = 0; j < kAhead; j++) if (f0 + j < P.nframes) dst[(f0 + j) * kBands] = e[j];
   }
 }
 
@@ -403,10 +405,11 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     int64_t gx = dp.nframes < 2048 ? dp.nframes : 2048;
     WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
-    WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)((nchan * kBands + 63) / 64)), dim3(64), s, (const float*)rms.as<float>(),
+    WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
                plan.as<DeharshPlan>(), nchan, gdb.as<double>());
   }
-  const int64_t seg = tuning().dh_seg_frames, warm = tuning().dh_warm_frames;
+  const int64_t warm = tuning().dh_warm_frames;
+  const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, 8192);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
   WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)nseg, (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
              winb.as<float>(), (const double*)gdb.as<double>(), pre_gain, seg, warm);

@@ -449,8 +449,9 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
                       const double* gains_dev, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  const int64_t seg = tuning().env_seg_tiles, warm = tuning().sc_warm_tiles;
+  const int64_t warm = tuning().sc_warm_tiles;
   const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().env_seg_tiles);
   const unsigned nseg = (unsigned)((ntiles + seg - 1) / seg);
   if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
   else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
@@ -462,7 +463,8 @@ int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  const int64_t seg = tuning().env_seg_tiles, warm = tuning().lim_warm_tiles;
+  const int64_t warm = tuning().lim_warm_tiles;
+  const int64_t seg = pick_segment_tiles(ntracks, (n + L + kTile - 1) / kTile, warm, tuning().env_seg_tiles);
   if (preserve) {
     const unsigned nseg = (unsigned)(((n + kTile - 1) / kTile + seg - 1) / seg);
     if (nch == 2) WAM_LAUNCH("k_lim_tm", k_lim_tm<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, tm, seg, warm);

@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int 
   extern __shared__ float sm[];
   float* re = sm; float* im = sm + nfft; float* sp = sm + 2 * nfft;
   const int half = nfft >> 1;
+  in += (int64_t)blockIdx.y * nch * n;                                 // track
+  out_db += (int64_t)blockIdx.y * nframes * half;
+  if (cols) cols += (int64_t)blockIdx.y * nframes * 256;
   for (int64_t f = blockIdx.x; f < nframes; f += gridDim.x) {
     const int64_t pos = f * hop;
     __syncthreads();
@@ -291,19 +294,19 @@ int64_t wam_stft_num_frames(int64_t n, int nfft, int hop) {
   return (n - nfft) / hop + 1;
 }
 
-int wam_stft_db(const float* const* ch, int nch, int64_t n, double sr, int nfft, int hop, float* out_db, float* columns) {
-  int rc = check_in(ch, nch, n); if (rc) return rc;
-  if (!out_db || nfft < 16 || nfft > 8192 || (nfft & (nfft - 1)) || hop < 1 || !(sr > 0)) { set_error("invalid STFT arguments (nfft must be a power of two in 16..8192)"); return WAM_ERR_INVALID; }
-  rc = ensure_device(); if (rc) return rc;
+// tables + launch for [ntracks][nch][n] on the device; out_db_dev [ntracks][nframes][nfft/2], cols_dev [ntracks][nframes][256] or NULL
+static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, double sr, int nfft, int hop, float* out_db_dev, float* cols_dev,
+                        hipStream_t stream) {
+  using namespace wam;
   const int64_t nframes = wam_stft_num_frames(n, nfft, hop);
-  if (nframes == 0) return WAM_OK;
+  if (nframes == 0 || ntracks == 0) return WAM_OK;
   int bits = 0; while ((1 << bits) < nfft) bits++;
   const int half = nfft >> 1;
-  std::vector<float> ct(nfft), stb(nfft), win(nfft);
+  std::vector<float> tab(3 * (size_t)nfft);
   for (int i = 0; i < nfft; i++) {                                       // spectrogram.js:40-48
     const double ang = -2 * M_PI * i / nfft;
-    stb[i] = (float)std::sin(ang); ct[i] = (float)std::cos(ang);
-    win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / nfft)));
+    tab[i] = (float)std::cos(ang); tab[nfft + i] = (float)std::sin(ang);
+    tab[2 * nfft + i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / nfft)));
   }
   std::vector<StftRow> rows(256);
   {
@@ -320,24 +323,45 @@ int wam_stft_db(const float* const* ch, int nch, int64_t n, double sr, int nfft,
     }
   }
   const double add_db = 10 * std::log10(16.0) + (-20 * std::log10((double)nfft));   // correctionAC + fftNorm, :135-136
-  DevBuf in, tabs, rowsd, od, cd;
-  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
-  rc = tabs.alloc(sizeof(float) * 3 * nfft); if (rc) return rc;
-  WAM_HIP(hipMemcpyAsync(tabs.as<float>(), ct.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
-  WAM_HIP(hipMemcpyAsync(tabs.as<float>() + nfft, stb.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
-  WAM_HIP(hipMemcpyAsync(tabs.as<float>() + 2 * nfft, win.data(), sizeof(float) * nfft, hipMemcpyHostToDevice, nullptr));
+  DevBuf tabs, rowsd;
+  int rc = tabs.alloc(sizeof(float) * 3 * nfft); if (rc) return rc;
+  WAM_HIP(hipMemcpyAsync(tabs.p, tab.data(), sizeof(float) * 3 * nfft, hipMemcpyHostToDevice, stream));
   rc = rowsd.alloc(sizeof(StftRow) * 256); if (rc) return rc;
-  WAM_HIP(hipMemcpyAsync(rowsd.p, rows.data(), sizeof(StftRow) * 256, hipMemcpyHostToDevice, nullptr));
+  WAM_HIP(hipMemcpyAsync(rowsd.p, rows.data(), sizeof(StftRow) * 256, hipMemcpyHostToDevice, stream));
+  int64_t bx = nframes < 4096 ? nframes : 4096;
+  if (ntracks >= 64 && bx > 128) bx = 128;                               // enough workgroups from the track dimension
+  const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
+  prof_begin("k_stft", stream);
+  hipLaunchKernelGGL(k_stft, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), shmem, stream, in_dev, nch, n, nfft, bits, hop, nframes,
+                     (const float*)tabs.as<float>(), (const float*)(tabs.as<float>() + nfft), (const float*)(tabs.as<float>() + 2 * nfft),
+                     add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+  prof_end(stream);
+  WAM_HIP(hipGetLastError());
+  WAM_HIP(hipStreamSynchronize(stream));                                 // tables (host vectors, pool blocks) are released on return
+  return WAM_OK;
+}
+
+int wam_batch_stft_db_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sr, int nfft, int hop, float* out_db_dev,
+                          float* columns_dev, void* stream) {
+  if (!in_dev || !out_db_dev || ntracks < 1 || nch < 1 || nch > 2 || n < 0 || nfft < 16 || nfft > 8192 || (nfft & (nfft - 1)) || hop < 1 || !(sr > 0)) {
+    wam::set_error("invalid STFT arguments (nfft must be a power of two in 16..8192)"); return WAM_ERR_INVALID;
+  }
+  int rc = wam::ensure_device(); if (rc) return rc;
+  return stft_enqueue(in_dev, ntracks, nch, n, sr, nfft, hop, out_db_dev, columns_dev, (hipStream_t)stream);
+}
+
+int wam_stft_db(const float* const* ch, int nch, int64_t n, double sr, int nfft, int hop, float* out_db, float* columns) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out_db || nfft < 16 || nfft > 8192 || (nfft & (nfft - 1)) || hop < 1 || !(sr > 0)) { set_error("invalid STFT arguments (nfft must be a power of two in 16..8192)"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  const int64_t nframes = wam_stft_num_frames(n, nfft, hop);
+  if (nframes == 0) return WAM_OK;
+  const int half = nfft >> 1;
+  DevBuf in, od, cd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
   rc = od.alloc(sizeof(float) * (size_t)nframes * half); if (rc) return rc;
   if (columns) { rc = cd.alloc(sizeof(float) * (size_t)nframes * 256); if (rc) return rc; }
-  int64_t bx = nframes < 4096 ? nframes : 4096;
-  const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
-  prof_begin("k_stft", nullptr);
-  hipLaunchKernelGGL(k_stft, dim3((unsigned)bx), dim3(256), shmem, nullptr, (const float*)in.as<float>(), nch, n, nfft, bits, hop, nframes,
-                     (const float*)tabs.as<float>(), (const float*)(tabs.as<float>() + nfft), (const float*)(tabs.as<float>() + 2 * nfft),
-                     add_db, od.as<float>(), (const StftRow*)rowsd.as<StftRow>(), columns ? cd.as<float>() : nullptr);
-  prof_end(nullptr);
-  WAM_HIP(hipGetLastError());
+  rc = stft_enqueue(in.as<float>(), 1, nch, n, sr, nfft, hop, od.as<float>(), columns ? cd.as<float>() : nullptr, nullptr); if (rc) return rc;
   WAM_HIP(hipMemcpy(out_db, od.p, sizeof(float) * (size_t)nframes * half, hipMemcpyDeviceToHost));
   if (columns) WAM_HIP(hipMemcpy(columns, cd.p, sizeof(float) * (size_t)nframes * 256, hipMemcpyDeviceToHost));
   return WAM_OK;

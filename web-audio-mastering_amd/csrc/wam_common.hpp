@@ -61,9 +61,9 @@ void prof_end(hipStream_t s);
 // Time-segmentation knobs (include/wam_synth.h: wam_tune).  Defaults are the production values; tests shrink them so
 // that short fixtures cross segment seams.
 struct Tuning {
-  int64_t dh_seg_frames = 512;    // de-harsh synthesis: frames per workgroup segment
+  int64_t dh_seg_frames = 0;      // de-harsh synthesis: frames per workgroup segment, 0 = pick_segment_tiles() over frames
   int64_t dh_warm_frames = 48;    // frames re-run before a segment to rebuild the resonance EMA (0.7^48 = 4e-8) and the overlap-add ring
-  int64_t env_seg_tiles = 64;     // soft-clip / limiter envelopes: tiles (4096 samples) per segment
+  int64_t env_seg_tiles = 0;      // soft-clip / limiter envelopes: tiles (4096 samples) per segment, 0 = pick_segment_tiles()
   int64_t sc_warm_tiles = 3;      // soft-clip release: exp(-12288/480) = 8e-12
   int64_t lim_warm_tiles = 25;    // limiter release 100 ms / peak follower 50 ms: exp(-102400/4800) = 5e-10
   int64_t fx_seg_tiles = 0;       // exciter / warmth / punch: tiles per segment, 0 = pick_segment_tiles()
@@ -75,16 +75,21 @@ struct Tuning {
 };
 Tuning& tuning();
 
-// Tiles per segment for the kernels that walk a (track, channel) in time order: enough segments that the launch has
-// about `want_wgs` workgroups, but never so short that the warm-up re-run costs more than a quarter of the work.
+// Tiles per segment for the kernels that walk a (track, channel) in time order.  With many walkers: enough segments
+// for about `want_wgs` workgroups, but never so short that the warm-up re-run costs more than a quarter of the work.
+// With few walkers (one track) the chip is idle anyway, so latency wins: segments shrink until the launch has one
+// workgroup per resident slot (2 per CU), whatever the warm-up overhead.
 inline int64_t pick_segment_tiles(int64_t walkers, int64_t ntiles, int64_t warm, int64_t override_tiles, int64_t want_wgs = 2048) {
   if (override_tiles > 0) return override_tiles;
   if (ntiles < 1) return 1;
-  int64_t nseg = (want_wgs + walkers - 1) / (walkers > 0 ? walkers : 1);
-  if (nseg < 1) nseg = 1;
-  int64_t seg = (ntiles + nseg - 1) / nseg;
-  if (seg < 4 * warm) seg = 4 * warm;
-  if (seg < 8) seg = 8;
+  if (walkers < 1) walkers = 1;
+  const int64_t slots = 512;
+  const int64_t seg_many = (ntiles * walkers + want_wgs - 1) / want_wgs;
+  int64_t seg_fill = (ntiles * walkers + slots - 1) / slots;
+  if (seg_fill < 8) seg_fill = 8;
+  int64_t floor_seg = 4 * warm < seg_fill ? 4 * warm : seg_fill;
+  int64_t seg = seg_many > floor_seg ? seg_many : floor_seg;
+  if (seg < 1) seg = 1;
   return seg;
 }
 
