@@ -36,18 +36,18 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
 
 // ---- launchers (chain_*.hip).  All buffers are device pointers, layout [ntracks][nch][n]. ----
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
-                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s);
+                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, double sr, hipStream_t s);
 
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
-                      const double* gains_dev, hipStream_t s);
+                      const double* gains_dev, double sr, hipStream_t s);
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
-                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s);
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s);
 
-int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, hipStream_t s);
+int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s);
 int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const HeavyPlan& hp_host, unsigned* winpeak, float* sm, float* env,
                      double pre_gain, hipStream_t s);
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
-                       const float* env, double pre_gain, hipStream_t s);
+                       const float* env, double pre_gain, double sr, hipStream_t s);
 void make_heavy_plan(double sr, int64_t n, HeavyPlan* p);
 #define WAM_HAVE_DEHARSH 1
 int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n, double sr, double pre_gain, hipStream_t s);

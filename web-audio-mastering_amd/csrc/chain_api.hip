@@ -136,7 +136,7 @@ static int run_front_only(const float* const* ch, int nch, int64_t n, double sr,
   rc = ensure_device(); if (rc) return rc;
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan; rc = upload_plan(fp, plan, nullptr); if (rc) return rc;
-  rc = enqueue_front(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<FrontPlan>(), fp.do_glue, nullptr, nullptr, 0, nullptr, 1.0, nullptr);
+  rc = enqueue_front(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<FrontPlan>(), fp.do_glue, nullptr, nullptr, 0, nullptr, 1.0, sr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
@@ -250,20 +250,20 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
   if (do_exc) {
     rc = prog(0.3, "Applying exciter..."); if (rc) return rc;
     float* dst = next_dst();
-    rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, stream); if (rc) return rc;
+    rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, sr, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
   if (do_warm) {
     rc = prog(0.45, "Applying multiband saturation..."); if (rc) return rc;
     rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream); if (rc) return rc;
     float* dst = next_dst();
-    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 1, 0, wenv.as<float>(), pending_gain, stream); if (rc) return rc;
+    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 1, 0, wenv.as<float>(), pending_gain, sr, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
   if (do_punch) {
     rc = prog(0.55, "Applying multiband transient..."); if (rc) return rc;
     float* dst = next_dst();
-    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 0, 1, nullptr, pending_gain, stream); if (rc) return rc;
+    rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 0, 1, nullptr, pending_gain, sr, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
 
@@ -288,7 +288,7 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     {
       float* dst = next_dst();
       if (fp.do_meter) WAM_HIP(hipMemsetAsync(M1.hopsums, 0, M1.hopsums_bytes, stream));
-      rc = enqueue_front(src, dst, T, nch, n, fp_d, fp.do_glue, M1.plan, M1.hopsums, M1.hop_stride, M1.peaks, pending_gain, stream); if (rc) return rc;
+      rc = enqueue_front(src, dst, T, nch, n, fp_d, fp.do_glue, M1.plan, M1.hopsums, M1.hop_stride, M1.peaks, pending_gain, sr, stream); if (rc) return rc;
       src = dst; pending_gain = 1.0;
       if (fp.do_meter) { rc = enqueue_gate(mp, T, M1, stream); if (rc) return rc; final_meter = &M1; }
     }
@@ -300,12 +300,12 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     if (do_limit) {
       rc = prog(0.85, "Applying soft clipper..."); if (rc) return rc;
       float* dst = next_dst();
-      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, cp.L, have_gain ? gains_d : nullptr, stream); if (rc) return rc;
+      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, cp.L, have_gain ? gains_d : nullptr, sr, stream); if (rc) return rc;
       src = dst;
       rc = prog(0.95, "Applying final limiter..."); if (rc) return rc;
       dst = next_dst();
       WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, stream));
-      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, lp.L, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, stream); if (rc) return rc;
+      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, lp.L, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, stream); if (rc) return rc;
       src = dst;
       rc = enqueue_gate(mp, T, M2, stream); if (rc) return rc;
       final_meter = &M2;
@@ -384,7 +384,7 @@ int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double 
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan, genv; rc = upload_plan(cp, plan, nullptr); if (rc) return rc;
   rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
-  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), cp.L, nullptr, nullptr);
+  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), cp.L, nullptr, sr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
@@ -400,7 +400,7 @@ int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ce
   rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
   rc = tm.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
   rc = enqueue_limiter(st.in.as<float>(), st.out.as<float>(), tm.as<float>(), genv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L,
-                       preserve_transients != 0, nullptr, nullptr, 0, nullptr, nullptr);
+                       preserve_transients != 0, nullptr, nullptr, 0, nullptr, sr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
@@ -413,7 +413,7 @@ static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int 
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan; rc = upload_plan(hp, plan, nullptr); if (rc) return rc;
   if (which == 0) {
-    rc = enqueue_exciter(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1.0, nullptr);
+    rc = enqueue_exciter(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1.0, sr, nullptr);
   } else if (which == 1) {
     DevBuf wp, sm, env;
     const size_t nw = (size_t)(hp.w_nw > 0 ? hp.w_nw : 1);
@@ -422,11 +422,11 @@ static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int 
     rc = env.alloc(sizeof(float) * nw); if (rc) return rc;
     rc = enqueue_warm_env(st.in.as<float>(), 1, nch, n, hp, wp.as<unsigned>(), sm.as<float>(), env.as<float>(), 1.0, nullptr);
     if (rc) return rc;
-    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1, 0, env.as<float>(), 1.0, nullptr);
+    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 1, 0, env.as<float>(), 1.0, sr, nullptr);
     if (rc) return rc;
     return st.down(st.out.as<float>(), out, nullptr);
   } else {
-    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 0, 1, nullptr, 1.0, nullptr);
+    rc = enqueue_warm_punch(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<HeavyPlan>(), 0, 1, nullptr, 1.0, sr, nullptr);
   }
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);

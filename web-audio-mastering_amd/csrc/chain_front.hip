@@ -7,6 +7,7 @@
 // One workgroup per track (both channels: the side-chain and the M/S matrix link them).
 // Algorithmic traffic: 4 B read + 4 B written per sample-channel.
 #include "chain.hpp"
+#include <cmath>
 
 namespace wam {
 
@@ -174,10 +175,12 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
 }
 
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
-                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, hipStream_t s) {
+                  const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  const int64_t warm = do_glue ? tuning().glue_warm_tiles : tuning().meter_warm_tiles;
+  const int64_t mw = meter_warm((int64_t)std::floor(sr * 0.1), sr) + 1;          // +1: the 30 Hz high-pass settles slower than the K-weighting
+  const int64_t gw = scale_warm(tuning().glue_warm_tiles, sr);
+  const int64_t warm = (do_glue && gw > mw) ? gw : mw;
   const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().meter_seg_tiles);
   const dim3 grid(ntracks, (unsigned)((ntiles + seg - 1) / seg));
   if (nch == 2) WAM_LAUNCH("k_front", k_front<2>, grid, dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain, seg, warm);

@@ -313,9 +313,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
 }
 
 // ---------------------------------------------------------------------------- launchers
-int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, hipStream_t s) {
+int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().lti_warm_tiles;
+  const int64_t ntiles = (n + kTile - 1) / kTile, warm = scale_warm(tuning().lti_warm_tiles, sr);
   const int64_t seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
   WAM_LAUNCH("k_exciter", k_exciter, dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, n, plan_dev, pre_gain, seg, warm);
   return WAM_OK;
@@ -336,17 +336,17 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
 }
 
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
-                       const float* env, double pre_gain, hipStream_t s) {
+                       const float* env, double pre_gain, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
   if (do_warm && do_punch) { set_error("enqueue_warm_punch: one stage per call (segments read their neighbours' input: no in-place chaining)"); return WAM_ERR_INVALID; }
   if (in == out) { set_error("enqueue_warm_punch: in-place operation is not supported"); return WAM_ERR_INVALID; }
   const int64_t ntiles = (n + kTile - 1) / kTile;
   if (do_warm) {
-    const int64_t warm = tuning().lti_warm_tiles, seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+    const int64_t warm = scale_warm(tuning().lti_warm_tiles, sr), seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
     WAM_LAUNCH("k_warm", (k_warm_punch<true, false>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
   }
   if (do_punch) {
-    const int64_t warm = tuning().punch_warm_tiles, seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+    const int64_t warm = scale_warm(tuning().punch_warm_tiles, sr), seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
     WAM_LAUNCH("k_punch", (k_warm_punch<false, true>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
   }
   return WAM_OK;

@@ -8,6 +8,7 @@
 //       k_lim_gain : true-peak driven lookahead ramps (events are serial, each ramp wave-parallel) + release
 //       k_lim_apply: gain, oversampled soft knee, and the loudness / true-peak measurement of the result
 #include "chain.hpp"
+#include <cmath>
 
 namespace wam {
 
@@ -447,9 +448,9 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
 
 // ---------------------------------------------------------------------------- launchers
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
-                      const double* gains_dev, hipStream_t s) {
+                      const double* gains_dev, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  const int64_t warm = tuning().sc_warm_tiles;
+  const int64_t warm = scale_warm(tuning().sc_warm_tiles, sr);
   const int64_t ntiles = (n + L + kTile - 1) / kTile;
   const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().env_seg_tiles);
   const unsigned nseg = (unsigned)((ntiles + seg - 1) / seg);
@@ -461,9 +462,9 @@ int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int
 }
 
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
-                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, hipStream_t s) {
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
-  const int64_t warm = tuning().lim_warm_tiles;
+  const int64_t warm = scale_warm(tuning().lim_warm_tiles, sr);
   const int64_t seg = pick_segment_tiles(ntracks, (n + L + kTile - 1) / kTile, warm, tuning().env_seg_tiles);
   if (preserve) {
     const unsigned nseg = (unsigned)(((n + kTile - 1) / kTile + seg - 1) / seg);
@@ -475,7 +476,7 @@ int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntr
   if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
   else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
   {
-    const int64_t ntiles = (n + kTile - 1) / kTile, mwarm = tuning().meter_warm_tiles;
+    const int64_t ntiles = (n + kTile - 1) / kTile, mwarm = meter_warm((int64_t)std::floor(sr * 0.1), sr);
     const int64_t mseg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, mwarm, tuning().meter_seg_tiles);
     WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch, (unsigned)((ntiles + mseg - 1) / mseg)), dim3(kThreads), s, in, out, nch, n, plan_dev,
                (const float*)genv, meter_dev, hopsums, hop_stride, peaks, mseg, mwarm);

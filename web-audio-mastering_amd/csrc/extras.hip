@@ -222,7 +222,7 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
     rc = enqueue_gain_meter(in.as<float>(), tmp.as<float>(), 1, nch, n, gd.as<double>(), mp14, M2, nullptr); if (rc) return rc;
     WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, nullptr));
     rc = enqueue_limiter(tmp.as<float>(), o.as<float>(), tmb.as<float>(), gv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L, 1,
-                         M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, nullptr); if (rc) return rc;
+                         M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, nullptr); if (rc) return rc;
     rc = enqueue_gate(mp14, 1, M2, nullptr); if (rc) return rc;
     WAM_HIP(hipMemcpy(&g, M2.gate, sizeof(g), hipMemcpyDeviceToHost));
     res->peak_db = finish_peak_db(g);

@@ -210,7 +210,7 @@ int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_
                        const MeterScratch& s, hipStream_t stream) {
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
   if (n > 0) {
-    const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().meter_warm_tiles;
+    const int64_t ntiles = (n + kTile - 1) / kTile, warm = meter_warm(pl.hop, (double)pl.hop * 10.0);
     const int64_t seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().meter_seg_tiles);
     WAM_LAUNCH("k_gain_meter", k_gain_meter, dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), stream, in, out, nch, n, gains,
                (const MeterPlan*)s.plan, s.hopsums, s.hop_stride, s.peaks, seg, warm);
@@ -227,7 +227,7 @@ int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t
   WAM_HIP(hipMemcpyAsync(s.plan, &pl, sizeof(MeterPlan), hipMemcpyHostToDevice, stream));
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
   if (n > 0) {
-    const int64_t ntiles = (n + kTile - 1) / kTile, warm = tuning().meter_warm_tiles;
+    const int64_t ntiles = (n + kTile - 1) / kTile, warm = meter_warm(pl.hop, (double)pl.hop * 10.0);
     const int64_t seg = pick_segment_tiles((int64_t)ntracks * pl.nch, ntiles, warm, tuning().meter_seg_tiles);
     WAM_LAUNCH("k_meter", k_meter, dim3(ntracks * pl.nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), stream, in_dev, n, s.plan, s.hopsums,
                s.hop_stride, s.peaks, seg, warm);

@@ -2,6 +2,7 @@
 // libwam_hip.so: error reporting, device scratch, HIP call checking.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -74,6 +75,18 @@ struct Tuning {
   int64_t glue_warm_tiles = 50;   // glue follower, 250 ms release (+2 for the straddling hop)
 };
 Tuning& tuning();
+
+// Warm-up lengths are stated in tiles at 48 kHz; time constants are in seconds, so they grow with the sample rate.
+inline int64_t scale_warm(int64_t tiles48k, double sr) {
+  const double f = sr > 48000.0 ? sr / 48000.0 : 1.0;
+  return (int64_t)std::ceil((double)tiles48k * f - 1e-9);
+}
+// Fused meter: a straddling 100 ms hop reaches back ceil(hop / 4096) tiles; the rest of the budget (K-weighting settle) scales.
+inline int64_t meter_warm(int64_t hop, double sr) {
+  const int64_t reach = (hop + 4095) / 4096;
+  const int64_t settle = tuning().meter_warm_tiles > 2 ? tuning().meter_warm_tiles - 2 : 1;
+  return reach + scale_warm(settle, sr);
+}
 
 // Tiles per segment for the kernels that walk a (track, channel) in time order.  With many walkers: enough segments
 // for about `want_wgs` workgroups, but never so short that the warm-up re-run costs more than a quarter of the work.
