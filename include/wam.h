@@ -95,6 +95,12 @@ int64_t wam_lufs_num_blocks(int64_t n, double sample_rate);
  * dsp-worker.js:169-192, message FIND_TRUE_PEAK :1361).  dBTP, -INFINITY for silence. */
 int wam_true_peak_db(const float* const* ch, int nch, int64_t n, double* dbtp);
 
+/* measureShortTermLUFS(audioBuffer, position) / measureMomentaryLUFS(audioBuffer, position), web/lib/dsp/lufs.js:91-119
+ * and :128-171: the 3 s window at `position` seconds measured like a buffer of its own (filters from zero state, both
+ * gates), and the ungated K-weighted level of the 400 ms window.  -INFINITY when less than half a window is left. */
+int wam_short_term_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs);
+int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs);
+
 /* One pass over the input for both numbers (what app.js:865-866 asks for on load). */
 int wam_meter(const float* const* ch, int nch, int64_t n, double sample_rate,
               double fallback, double* lufs, double* dbtp);

@@ -24,7 +24,7 @@ function track(c) {
 }
 
 async function cpu() {
-  for (const name of ['measureLUFS', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
+  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
     'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
@@ -61,6 +61,8 @@ async function gpu() {
     ok(Number.isFinite(gp) ? Math.abs(p - gp) <= 0.01 : p === gp, `${name} tp ${p} vs ${gp}`);
     const r = await w.measureLUFS(ab);
     ok(Object.is(r.lufs, l), `${name} async lufs equals sync`);
+    for (const [pos, v] of (c.short_term || [])) { const g = wam.measureShortTermLUFS(ab, pos), want = num(v); ok(Number.isFinite(want) ? Math.abs(g - want) <= 0.01 : g === want, `${name} short-term @${pos}`); }
+    for (const [pos, v] of (c.momentary || [])) { const g = wam.measureMomentaryLUFS(ab, pos), want = num(v); ok(Number.isFinite(want) ? Math.abs(g - want) <= 0.01 : g === want, `${name} momentary @${pos}`); }
   }
   // full chain through the promise API, progress strings in worker order
   for (const name of ['chain_defaults_1s', 'chain_mono_1s', 'chain_preview_1s']) {

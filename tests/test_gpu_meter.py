@@ -98,3 +98,19 @@ def test_batch_meter_dev():
     for k in range(nt):
         _close(l[k], O.measure_lufs(tracks[k], sr), LUFS_TOL)
         _close(t[k], O.true_peak_db(tracks[k]), TP_TOL)
+
+
+def test_short_term_momentary(golden):
+    """a4: measureShortTermLUFS / measureMomentaryLUFS against the reference goldens and the oracle (incl. truncated windows)."""
+    c = golden["meter_10s_48k"]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    for pos, v in c["short_term"]:
+        got, want = wam.measure_short_term_lufs(x, c["sr"], pos), G.num(v)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-6
+    for pos, v in c["momentary"]:
+        got, want = wam.measure_momentary_lufs(x, c["sr"], pos), G.num(v)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-9
+    for pos in (0.0, 1.234, 7.9, 8.4, 9.7, 9.85, 12.0):
+        for fn, ofn in ((wam.measure_short_term_lufs, O.short_term_lufs), (wam.measure_momentary_lufs, O.momentary_lufs)):
+            got, want = fn(x, c["sr"], pos), ofn(x, c["sr"], pos)
+            assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-6

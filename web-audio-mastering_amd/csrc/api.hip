@@ -247,6 +247,40 @@ int wam_meter(const float* const* ch, int nch, int64_t n, double sample_rate, do
   return meter_dev(in.as<float>(), 1, nch, n, sample_rate, fallback, lufs, dbtp, nullptr, nullptr, nullptr, nullptr);
 }
 
+int wam_short_term_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  if (!lufs || !(sample_rate > 0) || !(position >= 0)) { set_error("invalid short-term arguments"); return WAM_ERR_INVALID; }
+  const int64_t win = (int64_t)std::floor(sample_rate * 3000 / 1000);              // lufs.js:93-96
+  const int64_t start = (int64_t)std::floor(position * sample_rate);
+  const int64_t end = start + win < n ? start + win : n;
+  if ((double)(end - start) < (double)win * 0.5) { *lufs = -INFINITY; return WAM_OK; }   // :98-100
+  const float* view[2] = { ch[0] + start, nch > 1 ? ch[1] + start : nullptr };
+  return wam_measure_lufs(view, nch, end - start, sample_rate, -14.0, lufs, nullptr, nullptr, nullptr);   // :118, default fallback
+}
+
+int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  if (!lufs || !(sample_rate > 0) || !(position >= 0)) { set_error("invalid momentary arguments"); return WAM_ERR_INVALID; }
+  const int64_t win = (int64_t)std::floor(sample_rate * 400 / 1000);               // lufs.js:130-133
+  const int64_t start = (int64_t)std::floor(position * sample_rate);
+  const int64_t end = start + win < n ? start + win : n;
+  if ((double)(end - start) < (double)win * 0.5) { *lufs = -INFINITY; return WAM_OK; }   // :135-137
+  rc = ensure_device(); if (rc) return rc;
+  const int64_t len = end - start;
+  const float* view[2] = { ch[0] + start, nch > 1 ? ch[1] + start : nullptr };
+  DevBuf in, sums;
+  rc = upload(view, nch, len, in, nullptr); if (rc) return rc;
+  rc = sums.alloc(sizeof(double) * 2); if (rc) return rc;
+  rc = enqueue_momentary(in.as<float>(), nch, len, sample_rate, sums.as<double>(), nullptr); if (rc) return rc;
+  double hs[2] = {0, 0};
+  WAM_HIP(hipMemcpy(hs, sums.p, sizeof(double) * nch, hipMemcpyDeviceToHost));
+  double ss = 0;
+  for (int c = 0; c < nch; c++) ss += hs[c];
+  const double ms = ss / ((double)len * nch);                                       // :167
+  *lufs = ms <= 0 ? -INFINITY : -0.691 + 10 * std::log10(ms);                       // :168-170
+  return WAM_OK;
+}
+
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate, double fallback,
                         double* lufs, double* dbtp, void* stream) {
   if (!in_dev || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }

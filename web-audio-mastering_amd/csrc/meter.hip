@@ -75,6 +75,27 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
   meter_finish(m, lds, peaks + chan);
 }
 
+// measureMomentaryLUFS (lufs.js:128-171): K-weighting from zero state over one <= 400 ms window, ungated sum of squares.
+// One thread per channel walks its <= 0.4 s sequentially, exactly as the reference's loops do (a window is ~19 k samples).
+struct MomentaryCoef { double s[5], h[5]; };
+__global__ void k_momentary(const float* __restrict__ in, int nch, int64_t len, MomentaryCoef q, double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nch) return;
+  const float* x = in + (int64_t)c * len;
+  double x1 = 0, x2 = 0, y1 = 0, y2 = 0, u1 = 0, u2 = 0, v1 = 0, v2 = 0, ss = 0;
+  for (int64_t i = 0; i < len; i++) {
+    const double xi = x[i];
+    const double y = q.s[0] * xi + q.s[1] * x1 + q.s[2] * x2 - q.s[3] * y1 - q.s[4] * y2;      // utils.js:17-22
+    x2 = x1; x1 = xi; y2 = y1; y1 = y;
+    const double ui = (double)f32r(y);
+    const double v = q.h[0] * ui + q.h[1] * u1 + q.h[2] * u2 - q.h[3] * v1 - q.h[4] * v2;
+    u2 = u1; u1 = ui; v2 = v1; v1 = v;
+    const double z = (double)f32r(v);
+    ss += z * z;
+  }
+  sums[c] = ss;
+}
+
 // Stage-8 gain per track from the gated loudness (normalizer.js:39-51).  gains[t] = 1 when
 // the loudness is not finite (silence: the reference returns its input) or normalisation is off.
 __global__ void k_norm_gain(const GateOut* __restrict__ gate, const MeterPlan* __restrict__ plan, int ntracks, double target,
@@ -216,6 +237,13 @@ int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_
                (const MeterPlan*)s.plan, s.hopsums, s.hop_stride, s.peaks, seg, warm);
   }
   return enqueue_gate(pl, ntracks, s, stream);
+}
+
+int enqueue_momentary(const float* in_dev, int nch, int64_t len, double sr, double* sums_dev, hipStream_t stream) {
+  const Biquad sh = k_high_shelf(sr, 1681.97, 4.0, 0.71), hp = rbj_pass(sr, 38.14, 0.5, true);   // constants.js:7-13
+  MomentaryCoef q = { { sh.b0, sh.b1, sh.b2, sh.a1, sh.a2 }, { hp.b0, hp.b1, hp.b2, hp.a1, hp.a2 } };
+  WAM_LAUNCH("k_momentary", k_momentary, dim3(1), dim3(64), stream, in_dev, nch, len, q, sums_dev);
+  return WAM_OK;
 }
 
 int enqueue_norm_gain(const MeterScratch& s, int ntracks, double target, double* gains, double* lufs_in, hipStream_t stream) {

@@ -30,6 +30,7 @@ int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t
 // out = f32(in * gains[track]) (out may be NULL, gains may be NULL) + metering + gate
 int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_t n, const double* gains, const MeterPlan& pl,
                        const MeterScratch& s, hipStream_t stream);
+int enqueue_momentary(const float* in_dev, int nch, int64_t len, double sr, double* sums_dev, hipStream_t stream);
 int enqueue_norm_gain(const MeterScratch& s, int ntracks, double target, double* gains, double* lufs_in, hipStream_t stream);
 int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream);
 double finish_lufs(const MeterPlan& pl, const GateOut& g);

@@ -54,6 +54,12 @@ const stage = (name, ab, params = []) => makeAB(addon().stageSync(name, chansOf(
 export function measureLUFS(audioBuffer, fallbackLufs = -14) {                       // lufs.js:17
   return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate, fallbackLufs).lufs;
 }
+export function measureShortTermLUFS(audioBuffer, position = 0) {                    // lufs.js:91
+  return addon().windowLufsSync(chansOf(audioBuffer), audioBuffer.sampleRate, position, false);
+}
+export function measureMomentaryLUFS(audioBuffer, position = 0) {                    // lufs.js:128
+  return addon().windowLufsSync(chansOf(audioBuffer), audioBuffer.sampleRate, position, true);
+}
 export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
   return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
 }

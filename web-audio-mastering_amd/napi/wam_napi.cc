@@ -171,6 +171,21 @@ Job* job_meter(napi_env env, napi_value* a) {       // (channels, sampleRate, fa
   j->finish = [](napi_env env, Job& j) { napi_value o; napi_create_object(env, &o); set_num(env, o, "lufs", j.d[2]); set_num(env, o, "peakDB", j.d[3]); return o; };
   return j.release();
 }
+Job* job_window_lufs(napi_env env, napi_value* a) {   // (channels, sampleRate, position, momentary) -> number
+  auto j = std::make_unique<Job>();
+  if (!get_audio(env, a[0], &j->in)) return nullptr;
+  napi_get_value_double(env, a[1], &j->d[0]);
+  j->d[1] = 0; napi_valuetype t; napi_typeof(env, a[2], &t); if (t == napi_number) napi_get_value_double(env, a[2], &j->d[1]);
+  bool mom = false; napi_value b; if (napi_coerce_to_bool(env, a[3], &b) == napi_ok) napi_get_value_bool(env, b, &mom);
+  j->i32[0] = mom ? 1 : 0;
+  j->work = [](Job& j) {
+    auto p = j.in.ptrs();
+    return j.i32[0] ? wam_momentary_lufs(p.data(), (int)p.size(), j.in.n, j.d[0], j.d[1], &j.d[2])
+                    : wam_short_term_lufs(p.data(), (int)p.size(), j.in.n, j.d[0], j.d[1], &j.d[2]);
+  };
+  j->finish = [](napi_env env, Job& j) { napi_value v; napi_create_double(env, j.d[2], &v); return v; };
+  return j.release();
+}
 Job* job_render(napi_env env, napi_value* a, bool with_progress) {   // (channels, sampleRate, settings, mode[, onProgress])
   auto j = std::make_unique<Job>();
   if (!get_audio(env, a[0], &j->in)) return nullptr;
@@ -317,6 +332,7 @@ napi_value Init(napi_env env, napi_value exports) {
     {"init", nullptr, init_dev, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"deviceCount", nullptr, device_count, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"meterSync", nullptr, sync_entry<job_meter>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"windowLufsSync", nullptr, sync_entry<job_window_lufs>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"meter", nullptr, async_entry<job_meter>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"renderChainSync", nullptr, sync_entry<build_render_sync>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"renderChain", nullptr, render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

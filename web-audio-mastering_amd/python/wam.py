@@ -138,6 +138,22 @@ def measure_lufs(chans, sr, fallback=-14.0, detail=False):
     return out.value
 
 
+def measure_short_term_lufs(chans, sr, position=0.0):
+    """measureShortTermLUFS(audioBuffer, position) - web/lib/dsp/lufs.js:91"""
+    pin, keep = _ptrs(chans)
+    out = C.c_double(0)
+    _check(lib().wam_short_term_lufs(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(position), C.byref(out)))
+    return out.value
+
+
+def measure_momentary_lufs(chans, sr, position=0.0):
+    """measureMomentaryLUFS(audioBuffer, position) - web/lib/dsp/lufs.js:128"""
+    pin, keep = _ptrs(chans)
+    out = C.c_double(0)
+    _check(lib().wam_momentary_lufs(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(position), C.byref(out)))
+    return out.value
+
+
 def find_true_peak(chans):
     """findTruePeak(audioBuffer) - web/lib/dsp/true-peak.js:46"""
     pin, keep = _ptrs(chans)
