@@ -26,7 +26,7 @@ function track(c) {
 async function cpu() {
   for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
-    'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
+    'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
   const w = new wam.DSPWorkerInterface();
   ok(w.isReady === false, 'not ready before init');
@@ -93,6 +93,24 @@ async function gpu() {
     const g = u8(c.out); let same = wav.length === 44 + g.length;
     for (let i = 0; same && i < g.length; i++) same = wav[44 + i] === g[i];
     ok(same, 'pcm24 bytes identical'); }
+  // the Worker-shaped adapter: the reference's message protocol (dsp-worker.js:1-9)
+  { const c = golden['chain_core_1s']; const ab = track(c);
+    const wk = new wam.WamWorker();
+    const got = await new Promise((resolve) => {
+      const msgs = [];
+      wk.onmessage = (e) => { msgs.push(e.data); if (e.data.type !== 'PROGRESS' && e.data.id === 8) resolve(msgs); };
+      wk.postMessage({ type: 'RENDER_FULL_CHAIN', id: 7, data: { channels: [ab.getChannelData(0), ab.getChannelData(1)], sampleRate: c.sr, settings: c.settings, mode: c.mode } });
+      wk.postMessage({ type: 'NO_SUCH_TYPE', id: 8, data: {} });
+    });
+    const reply = got.find((m) => m.id === 7 && m.type !== 'PROGRESS');
+    ok(reply && reply.success === true && Math.abs(reply.result.lufs - c.lufs) <= 0.01, 'worker protocol: chain reply');
+    ok(maxAbsDiff(reply.result.channels[0], f32(c.out[0])) <= 1e-5, 'worker protocol: chain audio');
+    const prog = got.filter((m) => m.id === 7 && m.type === 'PROGRESS');
+    ok(prog.length >= 5 && prog[prog.length - 1].progress === 1.0 && prog[prog.length - 1].status === 'Complete', 'worker protocol: progress ends with Complete');
+    ok(got.indexOf(reply) > got.indexOf(prog[prog.length - 1]), 'worker protocol: reply after last progress');
+    const bad = got.find((m) => m.id === 8);
+    ok(bad.success === false && bad.error === 'Unknown message type: NO_SUCH_TYPE', `worker protocol: unknown type, got '${bad.error}'`);
+    wk.terminate(); }
   // normalize + terminate semantics
   { const c = golden['meter_10s_48k']; const ab = track(c);
     const r = await w.normalize(ab, -14, -1);

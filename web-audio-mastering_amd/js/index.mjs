@@ -138,6 +138,48 @@ export function stftDb(audioBuffer, nfft = 4096, hop = 1024) {                  
   return addon().stftDb(chansOf(audioBuffer), audioBuffer.sampleRate, nfft, hop);
 }
 
+// ---- web/workers/dsp-worker.js as a Worker-shaped object ---------------------------------------------
+// `new WamWorker()` stands where the reference does `new Worker(new URL('./dsp-worker.js', ...))` (worker-interface.js:29-32):
+// same message protocol (dsp-worker.js:1-9) - request {type, id, data}, reply {id, success, result} or
+// {id, success: false, error}, progress {id, type: 'PROGRESS', progress, status} - one request at a time, FIFO.
+// Types on the hot path are served (MEASURE_LUFS, FIND_TRUE_PEAK, NORMALIZE, APPLY_LIMITER, RENDER_FULL_CHAIN,
+// dsp-worker.js:1355-1468); any other type is answered like the worker's default branch (:1670).
+export class WamWorker {
+  constructor(device = 0) { addon().init(device); this.onmessage = null; this.onerror = null; this._tail = Promise.resolve(); this._dead = false; }
+  _emit(data) { if (!this._dead && typeof this.onmessage === 'function') this.onmessage({ data }); }
+  postMessage(msg /*, transferables */) {
+    const { type, id, data } = msg;
+    const progress = (p, status) => this._emit({ id, type: 'PROGRESS', progress: p, status });
+    this._tail = this._tail.then(async () => {
+      if (this._dead) return;
+      try {
+        let result;
+        switch (type) {
+          case 'MEASURE_LUFS': result = { lufs: (await addon().meter(data.channels, data.sampleRate, -14)).lufs }; break;
+          case 'FIND_TRUE_PEAK': result = { peakDB: (await addon().meter(data.channels, 48000, -14)).peakDB }; break;
+          case 'NORMALIZE': result = await addon().normalize(data.channels, data.sampleRate, data.targetLUFS, data.ceilingDB); break;
+          case 'APPLY_LIMITER':
+            result = { channels: await addon().stage('limiter', data.channels, data.sampleRate,
+              [data.ceilingLinear || 0.891, data.lookaheadMs || 3, data.releaseMs || 100, data.kneeDB || 3, data.preserveTransients !== false ? 1 : 0]) };
+            break;
+          case 'RENDER_FULL_CHAIN': {
+            const r = await addon().renderChain(data.channels, data.sampleRate, data.settings, data.mode, (p, s) => { if (p < 1) progress(p, s); });
+            result = { channels: r.channels, lufs: r.lufs, measuredLufs: r.measuredLufs };
+            break;
+          }
+          default: throw new Error(`Unknown message type: ${type}`);
+        }
+        await new Promise((res) => setTimeout(res, 0));          // progress calls queued by the addon drain before the reply
+        progress(1.0, 'Complete');
+        this._emit({ id, success: true, result });
+      } catch (error) {
+        this._emit({ id, success: false, error: error.message });
+      }
+    });
+  }
+  terminate() { this._dead = true; }
+}
+
 // ---- web/workers/worker-interface.js ------------------------------------------------------
 export class DSPWorkerInterface {
   constructor() { this.worker = null; this.pending = new Map(); this.nextId = 0; this.isReady = false; this._tail = Promise.resolve(); }
