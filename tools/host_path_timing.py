@@ -1,0 +1,16 @@
+"""PCIe-inclusive timing of the host-pointer entry points on one 3-min stereo 48 kHz track."""
+import sys, time
+sys.path.insert(0, "web-audio-mastering_amd/python"); sys.path.insert(0, "tests")
+import torch, numpy as np, wam
+import oracle_lib as O
+sr, n = 48000, 48000 * 180
+x = O.synth(3, 2, n, sr, {"amp": 1.6, "clickAmp": 0.6})
+s = dict(wam.DEFAULT_SETTINGS, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1, eqHigh=2)
+wam.init(0)
+for name, fn in (("render_full_chain", lambda: wam.render_full_chain(x, sr, s, "export")), ("meter", lambda: wam.meter(x, sr)),
+                 ("encode_pcm24", lambda: wam.encode_pcm24(x))):
+    fn()
+    t0 = time.perf_counter(); k = 5
+    for _ in range(k): fn()
+    dt = (time.perf_counter() - t0) / k
+    print(f"{name}: {dt * 1e3:.1f} ms per 3-min track incl. H2D/D2H from pageable host memory = {180 / dt:.0f} x realtime")
