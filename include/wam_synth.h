@@ -41,6 +41,10 @@ int wam_tune(const char* key, int64_t value);
  * all idle blocks to the driver. */
 int wam_trim_workspace(void);
 
+/* Policy-iteration statistics, all zero unless the library was built with -DWAM_COUNT_ITERS (a measurement build needs
+ * -fgpu-rdc): out[2s] = solves, out[2s+1] = iterations; s = 0 follower, 1 follower pair, 2 release smoother. */
+int wam_debug_counters(uint64_t out[8], int reset);
+
 #ifdef __cplusplus
 }
 #endif

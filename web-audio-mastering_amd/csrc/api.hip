@@ -23,6 +23,9 @@ void set_error(const char* fmt, ...) {
 }
 
 Tuning& tuning() { static Tuning t; return t; }
+#ifdef WAM_COUNT_ITERS
+__device__ unsigned long long g_iter_stats[8];
+#endif
 
 // ---- workspace pool -----------------------------------------------------------
 struct PoolBlock { void* p; size_t bytes; int device; };
@@ -144,6 +147,15 @@ extern "C" {
 const char* wam_last_error(void) { return g_err.c_str(); }
 const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
 
+int wam_debug_counters(uint64_t out[8], int reset) {
+  for (int i = 0; i < 8; i++) out[i] = 0;
+#ifdef WAM_COUNT_ITERS
+  WAM_HIP(hipDeviceSynchronize());
+  WAM_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(wam::g_iter_stats), sizeof(uint64_t) * 8));
+  if (reset) { uint64_t z[8] = {0}; WAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wam::g_iter_stats), z, sizeof(z))); }
+#endif
+  return WAM_OK;
+}
 int wam_trim_workspace(void) {
   std::vector<wam::PoolBlock> blocks;
   { std::lock_guard<std::mutex> lk(wam::g_pool_mu); blocks.swap(wam::g_pool); }

@@ -281,8 +281,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
         float a[C];                           // rectified input (f32 values, widened where used)
 #pragma unroll
         for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabsf(band[k]) : 0.0f;
-        double fe = follower_solve(a, fA, fR, Sf[b], slots.next());
-        double se = follower_solve(a, sA, sR, Ss[b], slots.next());
+        double fe, se;
+        follower_solve2(a, fA, fR, Sf[b], sA, sR, Ss[b], slots.next(), fe, se);
         double u[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {

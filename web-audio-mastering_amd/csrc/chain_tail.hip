@@ -63,6 +63,8 @@ __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ i
   for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
+    // pass 1: which (channel, sample) pairs are over the threshold - one compare per sample, no arithmetic behind it
+    unsigned ev = 0;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float v[C];
@@ -70,24 +72,28 @@ __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ i
 #pragma unroll
       for (int k = 0; k < C; k++) {
         const double a = fabs((double)f32r((double)v[k] * G));
-        if (a > P.thr_lin && base + k < n) {
-          // soft-clipper.js:200-207
-          const double excess = a - P.thr_lin;
-          const double normalized = excess / P.range_div;
-          const double sat = tanh_fast(normalized * P.drive);
-          const double target = P.thr_lin + sat * P.range;
-          const double red1 = target / a - 1.0;
-          const int64_t i = base + k;
-          const int wp = threadIdx.x * C + k;            // window index of sample i - L
-          if (i >= L) {
-#pragma unroll 1
-            for (int m = 0; m <= L; m++) atomicMin(&gwin[wp + m], __float_as_uint(f32r(1.0 + red1 * rt[m])));
-          } else {                                        // ramp clipped at the start of the track: start = 0
-            const double den = (double)(i > 1 ? i : 1);
-#pragma unroll 1
-            for (int64_t j = 0; j <= i; j++) atomicMin(&gwin[L + (int)(j - tile_base)], __float_as_uint(f32r(1.0 + red1 * ((double)j / den))));
-          }
-        }
+        if (a > P.thr_lin && base + k < n) ev |= 1u << (c * C + k);
+      }
+    }
+    // pass 2 (rare: ~1e-4 of the samples of a hot master): one rolled loop over the set bits, the sample re-read from L2
+    while (ev) {
+      const int bit = __ffs((int)ev) - 1;
+      ev &= ev - 1;
+      const int c = bit / C, k = bit % C;
+      const int64_t i = base + k;
+      const double a = fabs((double)f32r((double)in[(trk * NCH + c) * n + i] * G));
+      // soft-clipper.js:200-207
+      const double excess = a - P.thr_lin;
+      const double normalized = excess / P.range_div;
+      const double sat = tanh_fast(normalized * P.drive);
+      const double target = P.thr_lin + sat * P.range;
+      const double red1 = target / a - 1.0;
+      const int wp = threadIdx.x * C + k;            // window index of sample i - L
+      if (i >= L) {
+        for (int m = 0; m <= L; m++) atomicMin(&gwin[wp + m], __float_as_uint(f32r(1.0 + red1 * rt[m])));
+      } else {                                        // ramp clipped at the start of the track: start = 0
+        const double den = (double)(i > 1 ? i : 1);
+        for (int64_t j = 0; j <= i; j++) atomicMin(&gwin[L + (int)(j - tile_base)], __float_as_uint(f32r(1.0 + red1 * ((double)j / den))));
       }
     }
     __syncthreads();

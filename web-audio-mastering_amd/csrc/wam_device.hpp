@@ -265,6 +265,7 @@ __device__ __forceinline__ void onepole_chunk(double u[C], const OnePole& q, dou
 // ---- affine scan (per-thread coefficients), used by the follower policy iteration ----
 // Each thread's chunk maps start value e to (al * e + be).  Returns this thread's
 // start value given the tile carry S; S advances to the next tile's carry.
+template <bool CLAMP1 = false>
 __device__ __forceinline__ double scan_affine(double al, double be, double& S, double* lds) {
   const int lane = lane_id(), wave = wave_id();
 #pragma unroll
@@ -281,11 +282,27 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
 #pragma unroll
   for (int k = 0; k < kWaves; k++) {
     w = lds[2 * k] * w + lds[2 * k + 1];
+    if (CLAMP1) w = fmin(w, 1.0);
     if (k + 1 == wave) my = w;
   }
   S = w;
-  return xa * my + xb;
+  double r = xa * my + xb;
+  // CLAMP1: the recurrence is min(rc cur + (1 - rc), 1): its values never exceed 1, but a composed map can by an ulp,
+  // and a start value of 1 + ulp would flip the "g < cur" test of a sample at gain 1.0 back and forth for ever
+  if (CLAMP1) r = fmin(r, 1.0);
+  return r;
 }
+
+// Iteration statistics of the policy iterations (a build with -DWAM_COUNT_ITERS; read with wam_debug_counters):
+// [2 site] = solves, [2 site + 1] = iterations; site 0 follower, 1 follower pair, 2 release smoother.
+#ifdef WAM_COUNT_ITERS
+extern __device__ unsigned long long g_iter_stats[8];
+__device__ __forceinline__ void count_iters(int site, int iters) {
+  if (threadIdx.x == 0) { atomicAdd(&g_iter_stats[2 * site], 1ull); atomicAdd(&g_iter_stats[2 * site + 1], (unsigned long long)iters); }
+}
+#else
+__device__ __forceinline__ void count_iters(int, int) {}
+#endif
 
 // ---- piecewise-affine recurrences: policy iteration ---------------------------------
 // A recurrence e[n] = f_n(e[n-1]) whose step is piecewise affine (attack/release
@@ -297,23 +314,29 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
 // that policy implies; the loop repeats until no thread's mask changes, at which
 // point start values, branches and maps are mutually consistent = the sequential
 // solution.  Returns this thread's start value; S = tile carry in/out.
-template <class Run>
+template <bool CLAMP1 = false, class Run>
 __device__ __forceinline__ double solve_piecewise(Run run, double guess, double& S, double* lds, int max_iter = 260) {
   const double S_in = S;
-  double start = guess;
-  for (int it = 0; it < max_iter; it++) {
+  double start = guess, prev = guess;
+  int it = 0;
+  for (; it < max_iter; it++) {
     double al, be;
     run(start, al, be);
     double Sc = S_in;
-    const double ns = scan_affine(al, be, Sc, lds);
+    const double ns = scan_affine<CLAMP1>(al, be, Sc, lds);
     // Fixed point: the maps composed under this iteration's branches reproduce the start values they
     // were run from, so branches, maps and start values are mutually consistent.  (Comparing bit
     // patterns: identical maps scan to identical values.)
     const int changed = __syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(start));   // also fences the reuse of lds
     S = Sc;
+    if (!changed) { start = ns; break; }
+    // A comparison that is a tie to the last bit can flip with the ulp its own flip causes: a 2-cycle between two
+    // start vectors that are both valid to rounding.  Detected from the 4th iteration on (one more vote), then ended.
+    if (it >= 3 && !__syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(prev))) { start = ns; break; }
+    prev = start;
     start = ns;
-    if (!changed) break;
   }
+  count_iters(CLAMP1 ? 2 : 0, it + 1);
   return start;
 }
 
@@ -337,6 +360,57 @@ __device__ __forceinline__ double follower_solve(const T a[C], double A, double 
   };
   return solve_piecewise(run, S, S, lds);
 }
+// Two followers over the same input (the fast and slow envelopes of the transient shaper), solved in one iteration
+// loop: their runs and scans interleave (instruction-level parallelism for the dependent chains) and they share the
+// barriers; the loop ends when both start values reproduce themselves.  lds: 16 doubles.
+template <class T>
+__device__ __forceinline__ void follower_solve2(const T a[C], double A1, double R1, double& S1, double A2, double R2, double& S2,
+                                                double* lds, double& start1, double& start2) {
+  const int lane = lane_id(), wave = wave_id();
+  const double S1_in = S1, S2_in = S2;
+  double s1 = S1, s2 = S2, p1 = S1, p2 = S2;
+  int it = 0;
+  for (; it < 260; it++) {
+    double al1 = 1, be1 = 0, al2 = 1, be2 = 0;
+#pragma unroll
+    for (int n = 0; n < C; n++) {
+      const double an = (double)a[n];
+      const double e1 = fma(al1, s1, be1), e2 = fma(al2, s2, be2);
+      const double c1 = (an > e1) ? A1 : R1, c2 = (an > e2) ? A2 : R2;
+      be1 = fma(c1, be1 - an, an); be2 = fma(c2, be2 - an, an);
+      al1 = c1 * al1; al2 = c2 * al2;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int d = 1 << k;
+      const double ta1 = __shfl_up(al1, d), tb1 = __shfl_up(be1, d), ta2 = __shfl_up(al2, d), tb2 = __shfl_up(be2, d);
+      if (lane >= d) { be1 = al1 * tb1 + be1; al1 = al1 * ta1; be2 = al2 * tb2 + be2; al2 = al2 * ta2; }
+    }
+    if (lane == 63) { lds[4 * wave] = al1; lds[4 * wave + 1] = be1; lds[4 * wave + 2] = al2; lds[4 * wave + 3] = be2; }
+    double xa1 = __shfl_up(al1, 1), xb1 = __shfl_up(be1, 1), xa2 = __shfl_up(al2, 1), xb2 = __shfl_up(be2, 1);
+    if (lane == 0) { xa1 = 1; xb1 = 0; xa2 = 1; xb2 = 0; }
+    __syncthreads();
+    double w1 = S1_in, w2 = S2_in, my1 = S1_in, my2 = S2_in;
+#pragma unroll
+    for (int k = 0; k < kWaves; k++) {
+      w1 = lds[4 * k] * w1 + lds[4 * k + 1];
+      w2 = lds[4 * k + 2] * w2 + lds[4 * k + 3];
+      if (k + 1 == wave) { my1 = w1; my2 = w2; }
+    }
+    const double n1 = xa1 * my1 + xb1, n2 = xa2 * my2 + xb2;
+    const int changed = __syncthreads_or((__double_as_longlong(n1) != __double_as_longlong(s1)) | (__double_as_longlong(n2) != __double_as_longlong(s2)));
+    S1 = w1; S2 = w2;
+    if (!changed) { s1 = n1; s2 = n2; break; }
+    if (it >= 3 && !__syncthreads_or((__double_as_longlong(n1) != __double_as_longlong(p1)) | (__double_as_longlong(n2) != __double_as_longlong(p2)))) {
+      s1 = n1; s2 = n2; break;                                  // 2-cycle on a last-bit tie, see solve_piecewise
+    }
+    p1 = s1; p2 = s2;
+    s1 = n1; s2 = n2;
+  }
+  count_iters(1, it + 1);
+  start1 = s1; start2 = s2;
+}
+
 // one follower step, for the final pass that materialises the envelope
 __device__ __forceinline__ double follower_step(double e, double a, double A, double R) {
   return (a > e) ? A * e + (1 - A) * a : R * e + (1 - R) * a;
@@ -365,7 +439,7 @@ __device__ __forceinline__ double release_solve(const float g[C], double rc, dou
     while (t) { if (t & 1) p *= b; b *= b; t >>= 1; }
     guess = 1 - p * (1 - S);
   }
-  return solve_piecewise(run, guess, S, lds);
+  return solve_piecewise<true>(run, guess, S, lds);
 }
 __device__ __forceinline__ double release_step(double cur, double g, double rc) {
   if (g < cur) return g;
