@@ -97,3 +97,23 @@ def test_batch_stft_dev_matches_single():
         ref, rcols = O.stft_db(tracks[t], sr, 4096, 1024, columns=True)
         assert np.max(np.abs(out[t].cpu().numpy() - ref)) <= 2e-5          # dB; same bar as test_stft
         assert np.max(np.abs(cols[t].cpu().numpy() - rcols)) <= 2e-5
+
+
+@pytest.mark.parametrize("nfft,hop", [(4096, 1024), (2048, 512)])
+def test_stft_register_blocked_is_bit_identical(nfft, hop):
+    """k_stft_fast regroups the reference's radix-2 stages but performs the same butterflies with the same f32 stores."""
+    sr = 48000
+    x = O.synth(73, 2, nfft + hop * 25 + 77, sr, {"amp": 1.2, "clickAmp": 0.5})
+    try:
+        fast, fcols = wam.stft_db(x, sr, nfft, hop, columns=True)
+        wam.tune("stft_literal", 1)
+        lit, lcols = wam.stft_db(x, sr, nfft, hop, columns=True)
+    finally:
+        wam.tune("reset")
+    assert np.array_equal(fast, lit) and np.array_equal(fcols, lcols)
+    mono_f = wam.stft_db([x[1]], sr, nfft, hop)
+    wam.tune("stft_literal", 1)
+    try:
+        assert np.array_equal(mono_f, wam.stft_db([x[1]], sr, nfft, hop))
+    finally:
+        wam.tune("reset")

@@ -179,6 +179,7 @@ int wam_tune(const char* key, int64_t value) {
   else if (k == "meter_seg_tiles") t.meter_seg_tiles = value;
   else if (k == "meter_warm_tiles" && value >= 3) t.meter_warm_tiles = value;
   else if (k == "glue_warm_tiles" && value >= 3) t.glue_warm_tiles = value;
+  else if (k == "stft_literal") t.stft_literal = value;
   else if (k == "reset") t = wam::Tuning();
   else { wam::set_error("wam_tune: unknown key or value out of range: %s = %lld", key, (long long)value); return WAM_ERR_INVALID; }
   return WAM_OK;

@@ -55,21 +55,23 @@ __device__ __forceinline__ void r4_butterfly(float2 a[4]) {
   }
 }
 
-// a[r] = input element g + 256 r (in registers).  Result in z (padded, natural order), visible after the final barrier.
-// Unnormalised in both directions.  The caller guarantees that nobody still reads z when this is entered.
+// a[r] = input element g + 256 r (in registers).  Passes alternate between two LDS arrays (one barrier per pass):
+// pass 0 writes z0, then z0 -> z1 -> z0 -> z1 -> z0; the result (padded, natural order) is in z0 and visible after the
+// final barrier.  Unnormalised in both directions.  The caller guarantees that nobody still reads z0 or z1 on entry.
 template <bool INV>
-__device__ __forceinline__ void fft1024(float2 a[4], float2* z, const float2* twA) {
+__device__ __forceinline__ void fft1024(float2 a[4], float2* z0, float2* z1, const float2* twA) {
   const int g = threadIdx.x;
   r4_butterfly<INV>(a);
 #pragma unroll
-  for (int r = 0; r < 4; r++) z[padz(4 * g + r)] = a[r];
+  for (int r = 0; r < 4; r++) z0[padz(4 * g + r)] = a[r];
   __syncthreads();
 #pragma unroll
   for (int s = 1; s < 5; s++) {
     const int Ls = 1 << (2 * s), shift = 8 - 2 * s;
+    const float2* src = (s & 1) ? z0 : z1;
+    float2* dst = (s & 1) ? z1 : z0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) a[r] = z[padz(g + 256 * r)];
-    __syncthreads();
+    for (int r = 0; r < 4; r++) a[r] = src[padz(g + 256 * r)];
     const int j = g & (Ls - 1);
 #pragma unroll
     for (int r = 1; r < 4; r++) {
@@ -79,7 +81,7 @@ __device__ __forceinline__ void fft1024(float2 a[4], float2* z, const float2* tw
     r4_butterfly<INV>(a);
     const int base = ((g - j) << 2) + j;
 #pragma unroll
-    for (int r = 0; r < 4; r++) z[padz(base + r * Ls)] = a[r];
+    for (int r = 0; r < 4; r++) dst[padz(base + r * Ls)] = a[r];
     __syncthreads();
   }
 }
@@ -100,17 +102,16 @@ __device__ __forceinline__ BinPair split_pair(float2 zk, float2 zm, float2 w) {
 __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                   const float2* __restrict__ twg, const float* __restrict__ wing,
                                                   float* __restrict__ band_rms, double pre_gain) {
-  __shared__ float2 z[kZ];
+  __shared__ float2 z[kZ], zb[kZ];
   __shared__ float2 tw[kTwA + kTwB];
-  __shared__ float win[kN];
   __shared__ float part[4][kBands];
   const DeharshPlan& P = *dp;
   const float2* twA = tw; const float2* twB = tw + kTwA;
+  const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   const int t = threadIdx.x;
   for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
-  for (int i = t; i < kN; i += 256) win[i] = wing[i];
   // bins of this thread: pairs k1 = t (t = 0: DC, and bin 512 in the second slot) and k2 = t + 256
   const int k1 = t, k2 = t + 256;
   const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, 
       if (!(v1 == v1)) v1 = 0.0f;
       a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));   // fft.js:43-45
     }
-    fft1024<false>(a, z, twA);
+    fft1024<false>(a, z, zb, twA);
     float m2[4];                                                   // |X|^2 of the four bins (dynamic-processor.js:456-460)
     {
       const float2 zk = z[padz(k2)], zm = z[padz(kM - k2)];
@@ -223,9 +224,8 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
                                                   const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
                                                   const float* __restrict__ wing, const double* __restrict__ band_env, double pre_gain,
                                                   int64_t seg_frames, int64_t warm) {
-  __shared__ float2 z[kZ];
+  __shared__ float2 z[kZ], zb[kZ];
   __shared__ float2 tw[kTwA + kTwB];
-  __shared__ float win[kN];
   __shared__ float xin[kN];      // input ring: sample s at xin[s & 2047]
   __shared__ float ola[kN];      // overlap-add ring
   __shared__ float bg[kBands];
@@ -236,8 +236,9 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
   float* y = out + chan * n;
   const int t = threadIdx.x;
   const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423
+  const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
   for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
-  for (int i = t; i < kN; i += 256) { win[i] = wing[i]; ola[i] = 0.0f; }
+  for (int i = t; i < kN; i += 256) ola[i] = 0.0f;
   auto load_in = [&](int64_t s) -> float {
     float v = (s < n) ? x[s] : 0.0f;
     if (pre_gain != 1.0) v = f32r((double)v * pre_gain);
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
       if (!(v1 == v1)) v1 = 0.0f;
       a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));
     }
-    fft1024<false>(a, z, twA);
+    fft1024<false>(a, z, zb, twA);
     // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
     const bool first = f == fs;            // the detector's first frame (:203-207); a warm start for later segments
     auto bin_gain = [&](float mag, float& av_state, int band) -> float {
@@ -321,13 +322,12 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; r++) a[r] = z[padz(t + 256 * r)];
-    __syncthreads();
-    fft1024<true>(a, z, twA);
+    fft1024<true>(a, zb, z, twA);             // pass 0 writes zb while others may still read z: no barrier in between
     // synthesis window + overlap-add (fft.js:63-65, dynamic-processor.js:483-487): z[m] = 1024 (y[2m], y[2m+1])
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int m = t + 256 * r, i = 2 * m;
-      const float2 zz = z[padz(m)];
+      const float2 zz = zb[padz(m)];
       const float pr0 = f32r((double)(zz.x * (1.0f / kM)) * (double)win[i]);
       const float pr1 = f32r((double)(zz.y * (1.0f / kM)) * (double)win[i + 1]);
       const int64_t s = pos + i;

@@ -136,6 +136,112 @@ __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int 
   }
 }
 
+// ---- the same transform, register-blocked -----------------------------------------------------------------
+// k_stft above walks the reference's loop nest literally: one LDS round trip and one barrier per radix-2 stage.
+// For the two sizes that matter (2048: the reference's analyser, 4096: BASELINE configs[4]) the stages are grouped:
+// a thread holds R = 2^NS points that are closed under NS consecutive stages (stride D between them), runs those
+// stages in registers, and the workgroup meets in LDS only between groups (4096: 4+4+4 stages, 2048: 3+3+3+2).
+// Every butterfly is the same expression on the same operands with the same f32 store as spectrogram.js:238-256,
+// so the results are bit-identical to k_stft; only the order in which independent butterflies run differs.
+__device__ __forceinline__ int padq(int i) { return i + (i >> 4); }
+
+// NS stages on v[0..R): element m sits at position base + D m of the (bit-reversed-input) array; low = base mod D.
+template <int R, int NS, int LOGN>
+__device__ __forceinline__ void stft_stages(float2 v[R], int logD, int low, const float2* __restrict__ tw) {
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int h = 1 << k;
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & h) continue;
+      const int kk = low + ((m & (h - 1)) << logD);                   // k of spectrogram.js:243 for this butterfly
+      const float2 w = tw[kk << (LOGN - 1 - logD - k)];               // (cos, sin)[k * step]
+      const double cw = w.x, sw = w.y;
+      const double xr = v[m + h].x, xi = v[m + h].y;
+      const double tr = xr * cw - xi * sw;
+      const double ti = xr * sw + xi * cw;
+      const double ar = v[m].x, ai = v[m].y;
+      v[m + h] = make_float2(f32r(ar - tr), f32r(ai - ti));
+      v[m] = make_float2(f32r(ar + tr), f32r(ai + ti));
+    }
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in, int nch, int64_t n, int hop, int64_t nframes,
+                                                   const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
+                                                   double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols) {
+  constexpr int N = 1 << LOGN, PT = N / 256, LP = LOGN - 8, half = N / 2;
+  __shared__ float2 z[N + N / 16];
+  __shared__ float2 tw[N / 2];
+  __shared__ float sp[N / 2];
+  const int t = threadIdx.x;
+  in += (int64_t)blockIdx.y * nch * n;
+  out_db += (int64_t)blockIdx.y * nframes * half;
+  if (cols) cols += (int64_t)blockIdx.y * nframes * 256;
+  for (int i = t; i < half; i += 256) tw[i] = make_float2(cosT[i], sinT[i]);
+  __syncthreads();
+  for (int64_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+    const int64_t pos = f * hop;
+    float2 v[PT];
+    // group 1: positions t PT .. t PT + PT - 1 of the bit-reversed array (spectrogram.js:121-123, :222-235)
+#pragma unroll
+    for (int m = 0; m < PT; m++) {
+      const int i = (int)(__brev((unsigned)(t * PT + m)) >> (32 - LOGN));
+      float mm;
+      if (nch >= 2) mm = f32r(0.5 * ((double)in[pos + i] + (double)in[n + pos + i])); else mm = in[pos + i];
+      v[m] = make_float2(f32r((double)mm * (double)win[i]), 0.0f);
+    }
+    stft_stages<PT, LP, LOGN>(v, 0, 0, tw);
+#pragma unroll
+    for (int m = 0; m < PT; m++) z[padq(t * PT + m)] = v[m];
+    __syncthreads();
+    // middle groups (4096: one, 2048: two): stride D = PT^g, R = PT points each; a task rewrites exactly the positions
+    // it read, so the workgroup only has to meet between groups
+    constexpr int LASTS = (LOGN % LP) ? (LOGN % LP) : LP, MID = (LOGN - LP - LASTS) / LP;
+    int logD = LP;
+#pragma unroll
+    for (int g = 0; g < MID; g++) {
+      const int D = 1 << logD;
+      const int low = t & (D - 1), base = ((t >> logD) << (logD + LP)) + low;
+#pragma unroll
+      for (int m = 0; m < PT; m++) v[m] = z[padq(base + (m << logD))];
+      stft_stages<PT, LP, LOGN>(v, logD, low, tw);
+#pragma unroll
+      for (int m = 0; m < PT; m++) z[padq(base + (m << logD))] = v[m];
+      __syncthreads();
+      logD += LP;
+    }
+    // last group: the remaining LOGN - logD stages, stride D = 2^logD, natural-order output
+    constexpr int RL = 1 << LASTS, TASKS = N / RL / 256;
+#pragma unroll
+    for (int q = 0; q < TASKS; q++) {
+      const int u = t + 256 * q;                       // = low: D = N / RL > u
+      float2 w4[RL];
+#pragma unroll
+      for (int m = 0; m < RL; m++) w4[m] = z[padq(u + m * (N / RL))];
+      stft_stages<RL, LASTS, LOGN>(w4, LOGN - LASTS, u, tw);
+#pragma unroll
+      for (int m = 0; m < RL / 2; m++) {               // bins below N / 2
+        const int i = u + m * (N / RL);
+        const double pw = (double)w4[m].x * (double)w4[m].x + (double)w4[m].y * (double)w4[m].y;
+        const double db = 10 * log10(pw + 1e-24) + add_db;              // spectrogram.js:135-141
+        const float o = f32r(db < -144 ? -144.0 : db);
+        sp[i] = o;
+        out_db[f * half + i] = o;
+      }
+    }
+    __syncthreads();                                   // sp complete; z free for the next frame
+    if (cols) {
+      const StftRow r = rows[t];
+      double o = -144;
+      if (r.valid) o = (double)sp[r.bin1] + ((double)sp[r.bin2] - (double)sp[r.bin1]) * r.frac;   // spectrogram.js:196-200
+      cols[f * 256 + t] = f32r(o);
+      __syncthreads();
+    }
+  }
+}
+
 static int check_in(const float* const* ch, int nch, int64_t n) {
   if (!ch || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
   for (int c = 0; c < nch; c++) if (!ch[c] && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
@@ -331,10 +437,17 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
   int64_t bx = nframes < 4096 ? nframes : 4096;
   if (ntracks >= 64 && bx > 128) bx = 128;                               // enough workgroups from the track dimension
   const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
+  const float* ct = tabs.as<float>(); const float* st = ct + nfft; const float* wn = ct + 2 * nfft;
   prof_begin("k_stft", stream);
-  hipLaunchKernelGGL(k_stft, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), shmem, stream, in_dev, nch, n, nfft, bits, hop, nframes,
-                     (const float*)tabs.as<float>(), (const float*)(tabs.as<float>() + nfft), (const float*)(tabs.as<float>() + 2 * nfft),
-                     add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+  if (nfft == 4096 && !tuning().stft_literal)
+    hipLaunchKernelGGL(k_stft_fast<12>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
+                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+  else if (nfft == 2048 && !tuning().stft_literal)
+    hipLaunchKernelGGL(k_stft_fast<11>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
+                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+  else
+    hipLaunchKernelGGL(k_stft, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), shmem, stream, in_dev, nch, n, nfft, bits, hop, nframes, ct, st, wn,
+                       add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
   prof_end(stream);
   WAM_HIP(hipGetLastError());
   WAM_HIP(hipStreamSynchronize(stream));                                 // tables (host vectors, pool blocks) are released on return

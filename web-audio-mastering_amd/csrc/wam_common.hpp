@@ -72,6 +72,7 @@ struct Tuning {
   int64_t punch_warm_tiles = 48;  // slow transient follower, 250 ms release: exp(-196608/12000) = 8e-8
   int64_t meter_seg_tiles = 0;    // kernels with a fused meter (k_meter, k_gain_meter, k_lim_apply, k_front): 0 = pick_segment_tiles()
   int64_t meter_warm_tiles = 4;   // a straddling 100 ms hop reaches back 1.17 tiles; K-weighting high-pass e^-20 per tile
+  int64_t stft_literal = 0;       // 1 = always use the stage-by-stage STFT kernel (the register-blocked one must equal it bit for bit)
   int64_t glue_warm_tiles = 50;   // glue follower, 250 ms release (+2 for the straddling hop)
 };
 Tuning& tuning();

@@ -398,10 +398,10 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
       if (k + 1 == wave) { my1 = w1; my2 = w2; }
     }
     const double n1 = xa1 * my1 + xb1, n2 = xa2 * my2 + xb2;
-    const int changed = __syncthreads_or((__double_as_longlong(n1) != __double_as_longlong(s1)) | (__double_as_longlong(n2) != __double_as_longlong(s2)));
+    const int changed = __syncthreads_or((int)(__double_as_longlong(n1) != __double_as_longlong(s1)) | (int)(__double_as_longlong(n2) != __double_as_longlong(s2)));
     S1 = w1; S2 = w2;
     if (!changed) { s1 = n1; s2 = n2; break; }
-    if (it >= 3 && !__syncthreads_or((__double_as_longlong(n1) != __double_as_longlong(p1)) | (__double_as_longlong(n2) != __double_as_longlong(p2)))) {
+    if (it >= 3 && !__syncthreads_or((int)(__double_as_longlong(n1) != __double_as_longlong(p1)) | (int)(__double_as_longlong(n2) != __double_as_longlong(p2)))) {
       s1 = n1; s2 = n2; break;                                  // 2-cycle on a last-bit tie, see solve_piecewise
     }
     p1 = s1; p2 = s2;
