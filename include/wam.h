@@ -181,6 +181,14 @@ int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double s
 int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out);
 int wam_wav_header(int nch, int64_t n, int sample_rate, int bits, uint8_t out44[44]);
 
+/* encodeWAV 16-bit branch, web/ui/encoder.js:97-115: interleaved little-endian int16, 2 * nch * n bytes, no header.
+ * dither_mode 0 = 'none', 1 = 'tpdf', 2 = 'noise-shaped' (error feedback 0.85, encoder.js:16,110-113).
+ * dither = nch * n values in LSB units, the values triangularDither() would return, one per sample-channel in
+ * interleaved order (the reference draws them from Math.random, encoder.js:10-30: pass that stream for identical
+ * bytes); NULL = an internal TPDF generator of the same distribution, keyed by `seed`. */
+enum { WAM_DITHER_NONE = 0, WAM_DITHER_TPDF = 1, WAM_DITHER_NOISE_SHAPED = 2 };
+int wam_encode_pcm16(const float* const* ch, int nch, int64_t n, int dither_mode, const float* dither, uint32_t seed, uint8_t* out);
+
 /* Spectrogram.process() per frame, web/ui/spectrogram.js:113-143,217-257, batched:
  * frames start at f * hop of the mono mix 0.5 (L + R) (the analyser's down-mix),
  * periodic Hann, dB per bin as spectrogram.js:135-142.  out[nframes][nfft / 2];

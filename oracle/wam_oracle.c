@@ -818,6 +818,32 @@ void ora_pcm24(const float* const* in, int nch, int64_t n, uint8_t* out) {
   }
 }
 
+/* ref: web/ui/encoder.js:92-115 encodeWAV, 16-bit branch.  mode 0 = 'none', 1 = 'tpdf', 2 = 'noise-shaped'.
+ * dither[j] = the j-th value triangularDither() returns (encoder.js:18-30), one per sample-channel in interleaved
+ * order; ignored for mode 0.  Math.max / Math.min propagate NaN, C's fmax / fmin do not: js_max / js_min below. */
+static double js_max(double a, double b) { if (a != a || b != b) return NAN; return a > b ? a : b; }
+static double js_min(double a, double b) { if (a != a || b != b) return NAN; return a < b ? a : b; }
+void ora_pcm16(const float* const* in, int nch, int64_t n, int mode, const float* dither, uint8_t* out) {
+  float err[2] = {0, 0};                         /* noiseShapeError: Float32Array(numChannels) */
+  int64_t off = 0, di = 0;
+  for (int64_t i = 0; i < n; i++) {
+    for (int c = 0; c < nch; c++) {
+      const double sample = js_max(-1, js_min(1, (double)in[c][i]));
+      const double scaled = sample * 32767;
+      double q = scaled;
+      if (mode == 2) q += (double)err[c];
+      if (mode != 0) q += (double)dither[di++];
+      double r = floor(q);
+      if (q - r >= 0.5) r += 1;                  /* Math.round */
+      double cl = js_max(-32768, js_min(32767, r));
+      int16_t v = (cl != cl) ? 0 : (int16_t)cl;  /* DataView.setInt16(NaN) stores 0 */
+      out[off] = (uint8_t)(v & 0xFF); out[off + 1] = (uint8_t)((v >> 8) & 0xFF);
+      if (mode == 2) err[c] = (float)js_max(-2, js_min(2, (q - cl) * 0.85));
+      off += 2;
+    }
+  }
+}
+
 /* ref: web/ui/encoder.js:74-86 WAV header */
 void ora_wav_header(int nch, int64_t n, int sr, int bits, uint8_t h[44]) {
   const uint32_t bps = (uint32_t)bits / 8, data = (uint32_t)(n * nch * bps);

@@ -60,6 +60,7 @@ void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* c
 void ora_warmth(const float* const* in, int nch, int64_t n, double sr, float* const* out);
 void ora_punch(const float* const* in, int nch, int64_t n, double sr, float* const* out);
 void ora_pcm24(const float* const* in, int nch, int64_t n, uint8_t* out);
+void ora_pcm16(const float* const* in, int nch, int64_t n, int mode, const float* dither, uint8_t* out);
 void ora_wav_header(int nch, int64_t n, int sr, int bits, uint8_t out[44]);
 void ora_stft_db(const float* const* in, int nch, int64_t n, double sr, int nfft, int hop, float* out_db, float* columns);
 int ora_render_chain(const float* const* in, int nch, int64_t n, double sr, const wam_settings* s, int mode,

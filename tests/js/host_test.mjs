@@ -93,6 +93,21 @@ async function gpu() {
     const g = u8(c.out); let same = wav.length === 44 + g.length;
     for (let i = 0; same && i < g.length; i++) same = wav[44 + i] === g[i];
     ok(same, 'pcm24 bytes identical'); }
+  // 16-bit WAV: 'none' is deterministic (reference golden); dithered modes with the reference's own draws supplied
+  { const c16 = JSON.parse(fs.readFileSync(path.join(DATA, 'pcm16.json'), 'utf8')).cases;
+    for (const name of ['hot_none', 'hot_tpdf', 'edge_noise_shaped', 'mono_tpdf']) {
+      const c = c16[name];
+      const ab = new wam.WamAudioBuffer({ numberOfChannels: c.nch, length: c.n, sampleRate: c.sr });
+      c.input.forEach((nme, i) => ab.copyToChannel(f32(nme), i));
+      const wav = wam.encodeWAV(ab, c.sr, 16, { ditherMode: c.mode, ditherSource: c.mode === 'none' ? undefined : f32(c.dither) });
+      const g = u8(c.out); let same = wav.length === 44 + g.length && Buffer.from(wav.subarray(0, 44)).toString('hex') === c.header_hex;
+      for (let i = 0; same && i < g.length; i++) same = wav[44 + i] === g[i];
+      ok(same, `pcm16 ${name} bytes identical`);
+    }
+    const c = c16['mono_tpdf'];
+    const ab = new wam.WamAudioBuffer({ numberOfChannels: 1, length: c.n, sampleRate: c.sr }); ab.copyToChannel(f32(c.input[0]), 0);
+    const w1 = wam.encodeWAV(ab, c.sr, 16, { ditherSeed: 7 }), w2 = wam.encodeWAV(ab, c.sr, 16, { ditherSeed: 7 }), w3 = wam.encodeWAV(ab, c.sr, 16, { ditherSource: 'math-random' });
+    ok(Buffer.compare(Buffer.from(w1), Buffer.from(w2)) === 0 && w3.length === w1.length, 'pcm16 seeded dither is reproducible'); }
   // the Worker-shaped adapter: the reference's message protocol (dsp-worker.js:1-9)
   { const c = golden['chain_core_1s']; const ab = track(c);
     const wk = new wam.WamWorker();

@@ -267,6 +267,16 @@ def wav_header(nch, n, sr, bits):
     return h
 
 
+def pcm16(chans, mode, dither=None):
+    n = len(chans[0])
+    pin, keep = chan_ptrs(chans)
+    out = np.empty(2 * len(chans) * n, dtype=np.uint8)
+    d = np.ascontiguousarray(dither, dtype=np.float32) if dither is not None else None
+    lib().ora_pcm16(pin, C.c_int(len(chans)), C.c_int64(n), C.c_int(mode), d.ctypes.data_as(FP) if d is not None else None,
+                    out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def stft_db(chans, sr, nfft, hop, columns=False):
     n = len(chans[0])
     pin, keep = chan_ptrs(chans)

@@ -117,3 +117,30 @@ def test_stft_register_blocked_is_bit_identical(nfft, hop):
         assert np.array_equal(mono_f, wam.stft_db([x[1]], sr, nfft, hop))
     finally:
         wam.tune("reset")
+
+
+def test_pcm16_modes_vs_reference_and_oracle():
+    """16-bit encoder branches through the C ABI: identical bytes to the reference (seeded Math.random goldens) and, on a
+    longer input that spans many noise-shaping runs, to the sequential oracle."""
+    import json, os
+    MODE = {"none": 0, "tpdf": 1, "noise-shaped": 2}
+    with open(os.path.join(G.DATA, "pcm16.json")) as f:
+        cases = json.load(f)["cases"]
+    for name, c in cases.items():
+        x = G.chans(c["input"])
+        d = None if c["mode"] == "none" else G.f32(c["dither"])[: c["nch"] * c["n"]]
+        got = wam.encode_pcm16(x, MODE[c["mode"]], d)
+        assert np.array_equal(got, G.u8(c["out"])), name
+    rng = np.random.default_rng(5)
+    n = 70001
+    x = O.synth(74, 2, n, 48000, {"amp": 1.9, "clickAmp": 0.8})
+    x[0][1000:1100] = np.nan                                             # NaN input: zeros out, and poisons the noise shaper's channel from there on
+    d = ((rng.random(2 * n) + rng.random(2 * n)) - 1).astype(np.float32)
+    for mode in (0, 1, 2):
+        assert np.array_equal(wam.encode_pcm16(x, mode, d), O.pcm16(x, mode, d)), mode
+    # internal generator: TPDF on (-1, 1): mean 0, variance 1/6, and it changes with the seed
+    z = [np.zeros(200000, dtype=np.float32)]
+    a = wam.encode_pcm16(z, 1, None, seed=1).view(np.int16).astype(np.float64)
+    b = wam.encode_pcm16(z, 1, None, seed=2).view(np.int16).astype(np.float64)
+    assert set(np.unique(a)) <= {-1.0, 0.0, 1.0} and not np.array_equal(a, b)
+    assert abs(a.mean()) < 0.01 and abs(np.mean(a == 0) - 0.75) < 0.01   # P(|d| < 0.5) = 0.75 for a triangular density

@@ -182,3 +182,21 @@ def test_eq_spec_defined_sanity():
     assert np.isfinite(np.stack(y)).all()
     flat = O.parametric_eq(x, sr, [0, 0, 0, 0, 0], cut_mud=False)
     same(flat, x)
+
+
+def _pcm16_cases():
+    import json, os
+    with open(os.path.join(G.DATA, "pcm16.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_pcm16_modes_vs_reference(golden):
+    """encodeWAV 16-bit branches (encoder.js:97-115): the reference run with a seeded Math.random (tests/golden/gen_pcm16.mjs)."""
+    MODE = {"none": 0, "tpdf": 1, "noise-shaped": 2}
+    for name, c in _pcm16_cases().items():
+        x = G.chans(c["input"])
+        got = O.pcm16(x, MODE[c["mode"]], G.f32(c["dither"]))
+        assert np.array_equal(got, G.u8(c["out"])), name
+        assert bytes(O.wav_header(c["nch"], c["n"], c["sr"], 16)).hex() == c["header_hex"]
+    S = golden["stages_hot"]["stages"]
+    assert np.array_equal(O.pcm16(G.chans(S["limiter"]["out"]), 0), G.u8(S["pcm16_none"]["out"]))

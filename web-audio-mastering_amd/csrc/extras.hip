@@ -81,6 +81,61 @@ __global__ __launch_bounds__(256) void k_pcm24(const float* __restrict__ in, int
   }
 }
 
+// ------------------------------------------------------------------ 16-bit quantiser (encoder.js:92-115)
+// One thread per run of kPcm16Run frames, both channels, in the reference's loop order.  'none' and 'tpdf' have no
+// state.  'noise-shaped' feeds 0.85 x the quantisation error of a channel into its next sample (f32 state): a
+// recurrence that contracts by 0.85 per sample and is rounded to f32, so a run that starts kPcm16Warm frames early
+// from zero error reaches the sequential state to the last bit long before its first stored sample (a difference of d
+// shrinks to 0.85^512 d = 1e-36 d; at the f32 grain of 3e-8 it dies out geometrically).
+constexpr int kPcm16Run = 2048, kPcm16Warm = 512;
+__device__ __forceinline__ double js_max(double a, double b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+__device__ __forceinline__ double js_min(double a, double b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+__device__ __forceinline__ float tpdf_seeded(uint32_t seed, uint64_t j) {      // (u1 + u2) - 1, u in [0, 1): the shape of encoder.js:13
+  auto h = [&](uint32_t a) { uint32_t x = (a + 1u) * 0x9E3779B1u ^ seed * 0x85EBCA77u ^ (uint32_t)(j >> 31) * 0xC2B2AE3Du;
+                             x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; };
+  const double u1 = (double)h((uint32_t)(2 * j)) * (1.0 / 4294967296.0), u2 = (double)h((uint32_t)(2 * j + 1)) * (1.0 / 4294967296.0);
+  return f32r((u1 + u2) - 1);
+}
+// first NaN sample per channel (n if none): in 'noise-shaped' mode a NaN turns the channel's error state into NaN for
+// good (encoder.js:110-113), so everything after it encodes as 0 - a dependence no warm-up can rebuild
+__global__ __launch_bounds__(256) void k_first_nan(const float* __restrict__ in, int64_t n, unsigned long long* __restrict__ first) {
+  const int64_t chan = blockIdx.y;
+  unsigned long long best = (unsigned long long)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = in[chan * n + i];
+    if (v != v) { best = (unsigned long long)i; break; }
+  }
+  if (best < (unsigned long long)n) atomicMin(&first[chan], best);
+}
+__global__ __launch_bounds__(256) void k_pcm16(const float* __restrict__ in, int nch, int64_t n, int mode, const float* __restrict__ dither,
+                                                uint32_t seed, const unsigned long long* __restrict__ first_nan, uint8_t* __restrict__ out) {
+  const int64_t run = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = run * kPcm16Run;
+  if (i0 >= n) return;
+  int64_t i1 = i0 + kPcm16Run; if (i1 > n) i1 = n;
+  int64_t iw = i0; if (mode == 2) { iw = i0 - kPcm16Warm; if (iw < 0) iw = 0; }
+  float err[2] = {0.0f, 0.0f};
+  if (mode == 2) for (int c = 0; c < nch; c++) if ((unsigned long long)iw > first_nan[c]) err[c] = NAN;
+  for (int64_t i = iw; i < i1; i++) {
+#pragma unroll 2
+    for (int c = 0; c < nch; c++) {
+      const double sample = js_max(-1.0, js_min(1.0, (double)in[(int64_t)c * n + i]));
+      double q = sample * 32767;
+      if (mode == 2) q += (double)err[c];
+      if (mode != 0) { const uint64_t j = (uint64_t)i * nch + c; q += (double)(dither ? dither[j] : tpdf_seeded(seed, j)); }
+      double r = floor(q);
+      if (q - r >= 0.5) r += 1;                                       // Math.round
+      const double cl = js_max(-32768.0, js_min(32767.0, r));
+      if (mode == 2) err[c] = f32r(js_max(-2.0, js_min(2.0, (q - cl) * 0.85)));
+      if (i >= i0) {
+        const int v = (cl != cl) ? 0 : (int)cl;
+        uint8_t* o = out + 2 * ((int64_t)i * nch + c);
+        o[0] = (uint8_t)(v & 0xFF); o[1] = (uint8_t)((v >> 8) & 0xFF);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ spectrogram STFT
 struct StftRow { int bin1, bin2; double frac; int valid; };
 __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int nch, int64_t n, int nfft, int bits, int hop, int64_t nframes,
@@ -379,6 +434,34 @@ int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out) {
   const int64_t groups = (n + fpt - 1) / fpt;
   int64_t bx = (groups + 255) / 256; if (bx > 4096) bx = 4096;
   WAM_LAUNCH("k_pcm24", k_pcm24, dim3((unsigned)bx), dim3(256), nullptr, (const float*)in.as<float>(), nch, n, o.as<uint8_t>());
+  WAM_HIP(hipMemcpy(out, o.p, obytes, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
+int wam_encode_pcm16(const float* const* ch, int nch, int64_t n, int dither_mode, const float* dither, uint32_t seed, uint8_t* out) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!out || dither_mode < 0 || dither_mode > 2) { set_error("invalid 16-bit encoder arguments (dither_mode 0..2)"); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  if (n == 0) return WAM_OK;
+  DevBuf in, o, dd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  const size_t obytes = (size_t)2 * nch * (size_t)n;
+  rc = o.alloc(obytes); if (rc) return rc;
+  if (dither && dither_mode != 0) {
+    rc = dd.alloc(sizeof(float) * (size_t)nch * (size_t)n); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(dd.p, dither, sizeof(float) * (size_t)nch * (size_t)n, hipMemcpyHostToDevice, nullptr));
+  }
+  DevBuf fn;
+  rc = fn.alloc(sizeof(unsigned long long) * 2); if (rc) return rc;
+  if (dither_mode == 2) {
+    const unsigned long long init[2] = { (unsigned long long)n, (unsigned long long)n };
+    WAM_HIP(hipMemcpyAsync(fn.p, init, sizeof(init), hipMemcpyHostToDevice, nullptr));
+    int64_t bx = (n + 255) / 256; if (bx > 1024) bx = 1024;
+    WAM_LAUNCH("k_first_nan", k_first_nan, dim3((unsigned)bx, (unsigned)nch), dim3(256), nullptr, (const float*)in.as<float>(), n, fn.as<unsigned long long>());
+  }
+  const int64_t runs = (n + kPcm16Run - 1) / kPcm16Run;
+  WAM_LAUNCH("k_pcm16", k_pcm16, dim3((unsigned)((runs + 63) / 64)), dim3(64), nullptr, (const float*)in.as<float>(), nch, n, dither_mode,
+             (const float*)(dither && dither_mode != 0 ? dd.as<float>() : nullptr), seed, (const unsigned long long*)fn.as<unsigned long long>(), o.as<uint8_t>());
   WAM_HIP(hipMemcpy(out, o.p, obytes, hipMemcpyDeviceToHost));
   return WAM_OK;
 }

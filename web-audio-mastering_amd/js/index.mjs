@@ -111,19 +111,37 @@ export function removeDCOffset(channel) {                                       
   return r.dc[0];
 }
 
-// encodeWAV(audioBuffer, targetSampleRate, bitDepth, options) - web/ui/encoder.js:51.  24-bit only: the 16-bit
-// paths draw their dither from Math.random (encoder.js:13) and stay with the caller (SURVEY.md 8f rank 3).
+// encodeWAV(audioBuffer, targetSampleRate, bitDepth, options) - web/ui/encoder.js:51.  bitDepth 24, else 16 (:53).
+// 16-bit: options.ditherMode 'tpdf' (default) | 'noise-shaped' | 'none' (:36-40).  The reference draws its dither from
+// Math.random (:10-30); here options.ditherSource selects where the same triangular density comes from:
+//   'device' (default)  a seeded generator on the GPU (seed = options.ditherSeed, else one Math.random draw)
+//   'math-random'       (Math.random() + Math.random()) - 1 per sample-channel on this thread, exactly the reference's draws
+//   Float32Array        caller-supplied values in LSB units, one per sample-channel, interleaved order
 export function encodeWAV(audioBuffer, targetSampleRate, bitDepth, options = {}) {
-  if (bitDepth !== 24) throw new Error('wam: encodeWAV implements the 24-bit branch only');
   const n = audioBuffer.length, nch = audioBuffer.numberOfChannels;
+  const bits = bitDepth === 24 ? 24 : 16;
   const sampleRate = targetSampleRate || audioBuffer.sampleRate;
-  const pcm = addon().encodePcm24(chansOf(audioBuffer));
+  let pcm;
+  if (bits === 24) pcm = addon().encodePcm24(chansOf(audioBuffer));
+  else {
+    const req = options ? options.ditherMode : undefined;
+    const mode = req === 'none' ? 0 : (req === 'noise-shaped' ? 2 : 1);
+    let dither = null, seed = 0;
+    const src = options ? options.ditherSource : undefined;
+    if (mode !== 0) {
+      if (src instanceof Float32Array) dither = src;
+      else if (src === 'math-random') { dither = new Float32Array(n * nch); for (let j = 0; j < dither.length; j++) dither[j] = (Math.random() + Math.random()) - 1; }
+      else seed = (options && Number.isFinite(options.ditherSeed)) ? (options.ditherSeed >>> 0) : Math.floor(Math.random() * 4294967296);
+    }
+    pcm = addon().encodePcm16(chansOf(audioBuffer), mode, dither, seed);
+  }
+  const bps = bits / 8;
   const out = new Uint8Array(44 + pcm.length);
   const v = new DataView(out.buffer);
   const ws = (o, s) => { for (let i = 0; i < s.length; i++) v.setUint8(o + i, s.charCodeAt(i)); };
   ws(0, 'RIFF'); v.setUint32(4, 36 + pcm.length, true); ws(8, 'WAVE'); ws(12, 'fmt '); v.setUint32(16, 16, true);
-  v.setUint16(20, 1, true); v.setUint16(22, nch, true); v.setUint32(24, sampleRate, true); v.setUint32(28, sampleRate * nch * 3, true);
-  v.setUint16(32, nch * 3, true); v.setUint16(34, 24, true); ws(36, 'data'); v.setUint32(40, pcm.length, true);
+  v.setUint16(20, 1, true); v.setUint16(22, nch, true); v.setUint32(24, sampleRate, true); v.setUint32(28, sampleRate * nch * bps, true);
+  v.setUint16(32, nch * bps, true); v.setUint16(34, bits, true); ws(36, 'data'); v.setUint32(40, pcm.length, true);
   out.set(pcm, 44);
   return out;
 }

@@ -293,6 +293,28 @@ napi_value encode_pcm24(napi_env env, napi_callback_info info) {     // (channel
   NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
   return ta;
 }
+napi_value encode_pcm16(napi_env env, napi_callback_info info) {     // (channels, ditherMode 0|1|2, dither: Float32Array|null, seed) -> Uint8Array
+  napi_value a[4]; size_t argc = 4; napi_value undef; napi_get_undefined(env, &undef); for (auto& v : a) v = undef;
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  int32_t mode = 1; napi_get_value_int32(env, a[1], &mode);
+  const float* dither = nullptr;
+  bool is_ta = false; napi_is_typedarray(env, a[2], &is_ta);
+  if (is_ta) {
+    napi_typedarray_type tt; size_t count; void* data; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, a[2], &tt, &count, &data, &ab, &off) != napi_ok || tt != napi_float32_array || count < in.ch.size() * (size_t)in.n) {
+      napi_throw_range_error(env, nullptr, "dither must be a Float32Array of nch * n values"); return nullptr;
+    }
+    dither = (const float*)data;
+  }
+  uint32_t seed = 0; napi_get_value_uint32(env, a[3], &seed);
+  const size_t bytes = (size_t)2 * in.ch.size() * (size_t)in.n;
+  void* data; napi_value ab, ta; NAPI_CALL(env, napi_create_arraybuffer(env, bytes, &data, &ab));
+  auto p = in.ptrs();
+  if (wam_encode_pcm16(p.data(), (int)p.size(), in.n, mode, dither, seed, (uint8_t*)data)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+  return ta;
+}
 napi_value stft_db(napi_env env, napi_callback_info info) {          // (channels, sampleRate, nfft, hop) -> {frames, bins, db: Float32Array}
   napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
   Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
@@ -341,6 +363,7 @@ napi_value Init(napi_env env, napi_value exports) {
     {"stageSync", nullptr, sync_entry<job_stage>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stage", nullptr, async_entry<job_stage>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"encodePcm24", nullptr, encode_pcm24, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"encodePcm16", nullptr, encode_pcm16, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stftDb", nullptr, stft_db, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"dcOffset", nullptr, dc_offset, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };

@@ -268,6 +268,19 @@ def encode_pcm24(chans):
     return out
 
 
+def encode_pcm16(chans, dither_mode=1, dither=None, seed=0):
+    """encodeWAV 16-bit sample loop - web/ui/encoder.js:97-115.  dither_mode 0 none, 1 tpdf, 2 noise-shaped."""
+    pin, keep = _ptrs(chans)
+    n = len(keep[0])
+    out = np.empty(2 * len(keep) * n, dtype=np.uint8)
+    d = np.ascontiguousarray(dither, dtype=np.float32) if dither is not None else None
+    if d is not None and d.size < len(keep) * n:
+        raise WamError("dither needs nch * n values")
+    _check(lib().wam_encode_pcm16(pin, C.c_int(len(keep)), C.c_int64(n), C.c_int(dither_mode), d.ctypes.data_as(FP) if d is not None else None,
+                                  C.c_uint32(seed), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
 def wav_header(nch, n, sr, bits):
     h = np.zeros(44, dtype=np.uint8)
     _check(lib().wam_wav_header(C.c_int(nch), C.c_int64(n), C.c_int(sr), C.c_int(bits), h.ctypes.data_as(C.POINTER(C.c_uint8))))
