@@ -11,16 +11,20 @@
 
 namespace wam {
 
+// Filter state lives in LDS (lane powers [64][4] per distinct filter, tile carries [2] per instance): with up to nine
+// biquads per channel plus the meter, keeping it in registers cost 400+ VGPRs (one wave per SIMD, spills to AGPRs).
+enum { kFHpf = 0, kFEq0 = 1, kFSide = 7, kFShelf = 8, kFKhp = 9, kFNumFilters = 10 };
 template <int NCH>
-__global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in, float* __restrict__ out, int64_t n,
-                                                    const FrontPlan* __restrict__ fp, const MeterPlan* __restrict__ mp,
-                                                    double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
-                                                    double pre_gain, int64_t seg_tiles, int64_t warm) {
+__global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                       const FrontPlan* __restrict__ fp, const MeterPlan* __restrict__ mp,
+                                                       double* __restrict__ hopsums, int64_t hop_stride, double* __restrict__ peaks,
+                                                       double pre_gain, int64_t seg_tiles, int64_t warm) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ double lds_meter[NCH][kMeterLds];
+  __shared__ double Pl[kFNumFilters][64][4];
+  __shared__ double Sl[NCH * 9 + 1][2];            // per channel: hpf, 6 eq, shelf, khp; + side
   __shared__ float ctx[NCH * 9 + 1][kCtxFloats];   // per channel: hpf, 6 eq, lpf->eq, meter; + side
   __shared__ float bc[NCH];
-  const FrontPlan& P = *fp;
   const int64_t trk = blockIdx.x;
   const float* x[NCH]; float* y[NCH];
 #pragma unroll
@@ -28,22 +32,26 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
   const int lane = lane_id();
   LdsSlots slots(lds_scan);
 
-  // carried state
-  double Phpf[4], Peq[6][4], Pside[4], Plpf;
-  biquad_lane_power(P.hpf30, lane, Phpf);
-#pragma unroll
-  for (int b = 0; b < 6; b++) if (b < P.n_eq) biquad_lane_power(P.eq[b], lane, Peq[b]);
-  biquad_lane_power(P.side_hp, lane, Pside);
-  Plpf = onepole_lane_power(P.lpf18, lane);
-  double Shpf[NCH][2] = {}, Slpf[NCH] = {}, Seq[NCH][6][2] = {}, Sside[2] = {0, 0}, Senv = 0;
   // time segment (blockIdx.y): tiles [T0, T1) entered `warm` tiles early with cold state; the warm-up re-run rebuilds
   // the filters (30 Hz high-pass: e^-11 per tile) and, when the glue compressor is on, its 250 ms release follower
+  const int do_meter = fp->do_meter;
   const int64_t ntiles = (n + kTile - 1) / kTile;
-  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, P.do_meter ? mp->hop : 0, P.do_meter ? mp->nhops : 0);
-  MeterState ms[NCH];
-  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_init(ms[c], *mp, sg.Tw * kTile, &sg);
+  const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, do_meter ? mp->hop : 0, do_meter ? mp->nhops : 0);
+  if (wave_id() == 0) {
+    biquad_lane_power(fp->hpf30, lane, Pl[kFHpf][lane]);
+#pragma unroll
+    for (int b = 0; b < 6; b++) if (b < fp->n_eq) biquad_lane_power(fp->eq[b], lane, Pl[kFEq0 + b][lane]);
+    biquad_lane_power(fp->side_hp, lane, Pl[kFSide][lane]);
+  }
+  for (int i = threadIdx.x; i < (NCH * 9 + 1) * 2; i += kThreads) Sl[i >> 1][i & 1] = 0;
+  const double Plpf = onepole_lane_power(fp->lpf18, lane);
+  double Slpf[NCH] = {}, Senv = 0;
+  MeterStateL ms[NCH];
+  if (do_meter) for (int c = 0; c < NCH; c++) meter_init_l(ms[c], *mp, sg.Tw * kTile, sg, &Pl[kFShelf][0][0], &Pl[kFKhp][0][0], Sl[c * 9 + 7], Sl[c * 9 + 8]);
+  __syncthreads();
 
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
+    const FrontPlan& P = *reload_each_tile(fp);
     const bool first = t == sg.Tw;
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
         float pv[2];
         prev_ctx<2>(last, pv, ctx[c * 9 + 0], par, first);
         double s0, s1;
-        biquad_chunk(d, pv[1], pv[0], P.hpf30, Phpf, Shpf[c][0], Shpf[c][1], slots.next(), s0, s1);
+        biquad_chunk_lds(d, pv[1], pv[0], P.hpf30, &Pl[kFHpf][0][0], Sl[c * 9 + 0], slots.next(), s0, s1);
 #pragma unroll
         for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
         nb1 = (double)f32r(s0); nb2 = (double)f32r(s1); have_nb = true;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
           nb1 = pv[1]; nb2 = pv[0];
         }
         double s0, s1;
-        biquad_chunk(d, nb1, nb2, P.eq[b], Peq[b], Seq[c][b][0], Seq[c][b][1], slots.next(), s0, s1);
+        biquad_chunk_lds(d, nb1, nb2, P.eq[b], &Pl[kFEq0 + b][0][0], Sl[c * 9 + 1 + b], slots.next(), s0, s1);
 #pragma unroll
         for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
         nb1 = (double)f32r(s0); nb2 = (double)f32r(s1); have_nb = true;
@@ -110,18 +118,17 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
 
     if (P.do_glue) {
       // linked side-chain (dsp-worker.js:1287-1293), follower :1304-1312, gain :1318-1324
-      double a[C];
+      float a[C];
 #pragma unroll
       for (int k = 0; k < C; k++) {
         float sc;
         if (NCH >= 2) sc = f32r(((double)w[0][k] + (double)w[NCH - 1][k]) * 0.5); else sc = w[0][k];
-        a[k] = fabs((double)sc);
-        if (base + k >= n) a[k] = 0;
+        a[k] = (base + k < n) ? fabsf(sc) : 0.0f;
       }
       double e = follower_solve(a, P.glue_A, P.glue_R, Senv, slots.next());
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        e = follower_step(e, a[k], P.glue_A, P.glue_R);
+        e = follower_step(e, (double)a[k], P.glue_A, P.glue_R);
         float g = 1.0f;
         if (e > P.glue_thr) {
           // 10^(-(20 log10(e/thr)) (1 - 1/ratio) / 20) = (e/thr)^-(1 - 1/ratio); stored to a Float32Array by the reference
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
 #pragma unroll
         for (int k = 0; k < C; k++) d[k] = side[k];
         double s0, s1;
-        biquad_chunk(d, pv[1], pv[0], P.side_hp, Pside, Sside[0], Sside[1], slots.next(), s0, s1);
+        biquad_chunk_lds(d, pv[1], pv[0], P.side_hp, &Pl[kFSide][0][0], Sl[NCH * 9], slots.next(), s0, s1);
 #pragma unroll
         for (int k = 0; k < C; k++) side[k] = f32r(d[k]);
       }
@@ -163,15 +170,15 @@ __global__ __launch_bounds__(kThreads) void k_front(const float* __restrict__ in
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       if (t >= sg.T0) store_chunk(y[c], n, base, w[c]);
-      if (P.do_meter) {
+      if (do_meter) {
         const float last[3] = { w[c][C - 3], w[c][C - 2], w[c][C - 1] };
         float xp[3];
         prev_ctx<3>(last, xp, ctx[c * 9 + 8], par, first);
-        meter_chunk(w[c], xp, base, tile_base, n, *mp, ms[c], lds_meter[c], hopsums + (trk * NCH + c) * hop_stride);
+        meter_chunk_l(w[c], xp, base, tile_base, n, *reload_each_tile(mp), ms[c], lds_meter[c], hopsums + (trk * NCH + c) * hop_stride);
       }
     }
   }
-  if (P.do_meter) for (int c = 0; c < NCH; c++) meter_finish(ms[c], lds_meter[c], peaks + trk * NCH + c);
+  if (do_meter) for (int c = 0; c < NCH; c++) meter_finish(ms[c], lds_meter[c], peaks + trk * NCH + c);
 }
 
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,

@@ -69,32 +69,26 @@ __device__ __forceinline__ void meter_init(MeterState& m, const MeterPlan& pl, i
 // xp[0..3) = the three samples before the chunk (xp[2] = x[-1]); base = global
 // index of x[0]; n = track length.  lds: 16 doubles (two scan sites) + 4*kMaxK doubles.
 constexpr int kMeterLds = 16 + 4 * 4;
-__device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3], int64_t base, int64_t tile_base, int64_t n,
-                                            const MeterPlan& pl, MeterState& m, double* lds, double* hopsums) {
-  // ---- true peak (true-peak.js:53-65): history starts at zeros, evaluated for i >= 3
-  {
-    double y0 = xp[0], y1 = xp[1], y2 = xp[2];
-    double pk = m.peak;
+
+// ---- true peak (true-peak.js:53-65): history starts at zeros, evaluated for i >= 3
+template <class St>
+__device__ __forceinline__ void meter_peak_part(const float x[C], const float xp[3], int64_t base, int64_t n, St& m) {
+  double y0 = xp[0], y1 = xp[1], y2 = xp[2];
+  double pk = m.peak;
 #pragma unroll
-    for (int k = 0; k < C; k++) {
-      const double y3 = x[k];
-      const int64_t i = base + k;
-      if (i >= 3 && i < n && i >= m.own_from) pk = fmax(pk, true_peak4(y0, y1, y2, y3));
-      y0 = y1; y1 = y2; y2 = y3;
-    }
-    m.peak = pk;
+  for (int k = 0; k < C; k++) {
+    const double y3 = x[k];
+    const int64_t i = base + k;
+    if (i >= 3 && i < n && i >= m.own_from) pk = fmax(pk, true_peak4(y0, y1, y2, y3));
+    y0 = y1; y1 = y2; y2 = y3;
   }
-  // ---- K-weighting
-  double v[C];
-#pragma unroll
-  for (int k = 0; k < C; k++) v[k] = (base + k < n) ? (double)x[k] : 0.0;
-  double s0, s1;
-  biquad_chunk(v, (base - 1 >= 0) ? (double)xp[2] : 0.0, (base - 2 >= 0) ? (double)xp[1] : 0.0, pl.shelf, m.P1, m.S1a, m.S1b, lds, s0, s1);
-#pragma unroll
-  for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
-  double t0, t1;
-  biquad_chunk(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2a, m.S2b, lds + 8, t0, t1);
-  // ---- per-hop sums of squares
+  m.peak = pk;
+}
+
+// ---- per-hop sums of squares of the K-weighted chunk v[] (double values that are about to be rounded to f32)
+template <class St>
+__device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, int64_t tile_base, const MeterPlan& pl, St& m,
+                                               double* lds, double* hopsums) {
   const int64_t lim = pl.nhops * pl.hop;       // samples past the last complete hop never reach a block
   double sA = 0, sB = 0;
   const int64_t to_boundary = pl.hop - m.hop_off;   // samples of this chunk that belong to hop_idx
@@ -136,9 +130,59 @@ __device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3],
   while (m.hop_off >= pl.hop) { m.hop_off -= pl.hop; m.hop_idx++; }
 }
 
+__device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3], int64_t base, int64_t tile_base, int64_t n,
+                                            const MeterPlan& pl, MeterState& m, double* lds, double* hopsums) {
+  meter_peak_part(x, xp, base, n, m);
+  // ---- K-weighting
+  double v[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (base + k < n) ? (double)x[k] : 0.0;
+  double s0, s1;
+  biquad_chunk(v, (base - 1 >= 0) ? (double)xp[2] : 0.0, (base - 2 >= 0) ? (double)xp[1] : 0.0, pl.shelf, m.P1, m.S1a, m.S1b, lds, s0, s1);
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
+  double t0, t1;
+  biquad_chunk(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2a, m.S2b, lds + 8, t0, t1);
+  meter_hop_part(v, base, tile_base, pl, m, lds, hopsums);
+}
+
+// The same with the two filters' lane powers ([64][4] doubles each) and tile carries ([2] each) in LDS, for kernels
+// that are short of registers (k_front): see biquad_chunk_lds.
+struct MeterStateL {
+  const double* P1; const double* P2; double* S1; double* S2;
+  double peak;
+  int64_t hop_idx, hop_off, own_from, hop_lo, hop_hi;
+};
+__device__ __forceinline__ void meter_init_l(MeterStateL& m, const MeterPlan& pl, int64_t first_sample, const Segment& seg,
+                                             double* P1, double* P2, double* S1, double* S2) {
+  if (wave_id() == 0) { biquad_lane_power(pl.shelf, lane_id(), P1 + 4 * lane_id()); biquad_lane_power(pl.hp, lane_id(), P2 + 4 * lane_id()); }
+  if (threadIdx.x < 2) { S1[threadIdx.x] = 0; S2[threadIdx.x] = 0; }
+  m.P1 = P1; m.P2 = P2; m.S1 = S1; m.S2 = S2;
+  m.peak = 0;
+  m.own_from = seg.own_from; m.hop_lo = seg.hop_lo; m.hop_hi = seg.hop_hi;
+  const int64_t b = first_sample + (int64_t)threadIdx.x * C;
+  m.hop_idx = b / pl.hop;
+  m.hop_off = b - m.hop_idx * pl.hop;
+}
+__device__ __forceinline__ void meter_chunk_l(const float x[C], const float xp[3], int64_t base, int64_t tile_base, int64_t n,
+                                              const MeterPlan& pl, MeterStateL& m, double* lds, double* hopsums) {
+  meter_peak_part(x, xp, base, n, m);
+  double v[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (base + k < n) ? (double)x[k] : 0.0;
+  double s0, s1;
+  biquad_chunk_lds(v, (base - 1 >= 0) ? (double)xp[2] : 0.0, (base - 2 >= 0) ? (double)xp[1] : 0.0, pl.shelf, m.P1, m.S1, lds, s0, s1);
+#pragma unroll
+  for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
+  double t0, t1;
+  biquad_chunk_lds(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2, lds + 8, t0, t1);
+  meter_hop_part(v, base, tile_base, pl, m, lds, hopsums);
+}
+
 // Workgroup-wide final peak, max-ed into peaks[0] (zeroed before the launch; segments of one channel share it).
 // Non-negative doubles order like their bit patterns.
-__device__ __forceinline__ void meter_finish(MeterState& m, double* lds, double* peak_out) {
+template <class St>
+__device__ __forceinline__ void meter_finish(St& m, double* lds, double* peak_out) {
   const double w = wave_max(m.peak);
   __syncthreads();
   if (lane_id() == 0) lds[wave_id()] = w;
