@@ -101,6 +101,16 @@ int wam_true_peak_db(const float* const* ch, int nch, int64_t n, double* dbtp);
 int wam_short_term_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs);
 int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs);
 
+/* The same two measures at npos positions of one buffer in one call (one upload): lufs[i] = measureShortTermLUFS(ab,
+ * positions[i]) when `momentary` is 0, measureMomentaryLUFS(ab, positions[i]) otherwise (lufs.js:91-171).  This is the series
+ * a meter display polls; every window is still measured like a buffer of its own, exactly as the reference does per call. */
+int wam_lufs_series(const float* const* ch, int nch, int64_t n, double sample_rate, const double* positions, int npos,
+                    int momentary, double* lufs);
+
+/* extractPeaks(audioBuffer, numPeaks), web/ui/waveform.js:164-181: peaks[i] = max |x| over window i of floor(n / num_peaks)
+ * samples of channel 0 (the values are f32 magnitudes, exact); all zero when n < num_peaks. */
+int wam_extract_peaks(const float* ch0, int64_t n, int num_peaks, float* peaks);
+
 /* One pass over the input for both numbers (what app.js:865-866 asks for on load). */
 int wam_meter(const float* const* ch, int nch, int64_t n, double sample_rate,
               double fallback, double* lufs, double* dbtp);

@@ -190,6 +190,18 @@ double ora_momentary_lufs(const float* const* ch, int nch, int64_t n, double sr,
   return -0.691 + 10 * log10(ms);
 }
 
+/* ref: web/ui/waveform.js:164-181 extractPeaks (channel 0 only) */
+void ora_extract_peaks(const float* x, int64_t n, int num_peaks, float* peaks) {
+  const int64_t per = n / num_peaks;                       /* Math.floor(length / numPeaks) */
+  for (int i = 0; i < num_peaks; i++) {
+    const int64_t st = (int64_t)i * per;
+    int64_t en = st + per; if (en > n) en = n;
+    float mx = 0;
+    for (int64_t j = st; j < en; j++) { const float a = fabsf(x[j]); if (a > mx) mx = a; }
+    peaks[i] = mx;
+  }
+}
+
 /* ref: web/lib/dsp/dc-offset.js:13-31 detectDCOffset, :67-77 removeDCOffset */
 double ora_dc_detect(const float* x, int64_t n) {
   double s = 0;

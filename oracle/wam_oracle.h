@@ -38,6 +38,7 @@ double ora_true_peak_db(const float* const* ch, int nch, int64_t n);
 double ora_true_peak_sample(const double y[4]);
 double ora_short_term_lufs(const float* const* ch, int nch, int64_t n, double sr, double position);
 double ora_momentary_lufs(const float* const* ch, int nch, int64_t n, double sr, double position);
+void ora_extract_peaks(const float* x, int64_t n, int num_peaks, float* peaks);
 double ora_dc_detect(const float* x, int64_t n);
 double ora_dc_remove(float* x, int64_t n);
 

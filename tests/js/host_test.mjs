@@ -24,7 +24,7 @@ function track(c) {
 }
 
 async function cpu() {
-  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
+  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
     'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
@@ -64,6 +64,19 @@ async function gpu() {
     for (const [pos, v] of (c.short_term || [])) { const g = wam.measureShortTermLUFS(ab, pos), want = num(v); ok(Number.isFinite(want) ? Math.abs(g - want) <= 0.01 : g === want, `${name} short-term @${pos}`); }
     for (const [pos, v] of (c.momentary || [])) { const g = wam.measureMomentaryLUFS(ab, pos), want = num(v); ok(Number.isFinite(want) ? Math.abs(g - want) <= 0.01 : g === want, `${name} momentary @${pos}`); }
   }
+  // 8f rank 4: loudness series and waveform peaks against the reference run (tests/golden/gen_series.mjs)
+  { const S = JSON.parse(fs.readFileSync(path.join(DATA, 'series.json'), 'utf8')).cases;
+    const num = (v) => typeof v === 'string' ? ({ inf: Infinity, '-inf': -Infinity, nan: NaN })[v] : v;
+    const c = S['series_12s_48k']; const ab = track(c);
+    for (const [kind, key, tol] of [['short-term', 'short_term', 1e-6], ['momentary', 'momentary', 1e-9]]) {
+      const got = wam.measureLUFSSeries(ab, c.positions, kind);
+      let good = got.length === c.positions.length;
+      for (let i = 0; good && i < got.length; i++) { const w = num(c[key][i]); good = Number.isFinite(w) ? Math.abs(got[i] - w) <= tol : got[i] === w; }
+      ok(good, `series ${kind}`);
+    }
+    const p = S['peaks_full']; const pab = track({ idx: p.idx, nch: p.nch, n: p.n_synth, sr: p.sr, opts: p.opts });
+    const pk = wam.extractPeaks(pab, p.num_peaks), want = f32(p.peaks);
+    ok(Array.isArray(pk) && pk.length === want.length && pk.every((v, i) => v === want[i]), 'extractPeaks identical'); }
   // full chain through the promise API, progress strings in worker order
   for (const name of ['chain_defaults_1s', 'chain_mono_1s', 'chain_preview_1s']) {
     const c = golden[name]; const ab = track(c);

@@ -158,6 +158,13 @@ def momentary_lufs(chans, sr, pos):
     return lib().ora_momentary_lufs(pin, C.c_int(len(chans)), C.c_int64(len(chans[0])), C.c_double(sr), C.c_double(pos))
 
 
+def extract_peaks(x, num_peaks=800):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(num_peaks, dtype=np.float32)
+    lib().ora_extract_peaks(x.ctypes.data_as(FP), C.c_int64(len(x)), C.c_int(num_peaks), out.ctypes.data_as(FP))
+    return out
+
+
 def dc_detect(x):
     a = np.ascontiguousarray(x, dtype=np.float32)
     return lib().ora_dc_detect(a.ctypes.data_as(FP), C.c_int64(len(a)))

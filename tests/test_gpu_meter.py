@@ -114,3 +114,50 @@ def test_short_term_momentary(golden):
         for fn, ofn in ((wam.measure_short_term_lufs, O.short_term_lufs), (wam.measure_momentary_lufs, O.momentary_lufs)):
             got, want = fn(x, c["sr"], pos), ofn(x, c["sr"], pos)
             assert (got == want) if not np.isfinite(want) else abs(got - want) <= 1e-6
+
+
+def _series_cases():
+    import json, os
+    with open(os.path.join(G.DATA, "series.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_lufs_series(golden):
+    """8f rank 4: the short-term / momentary series in one call equals the reference's per-position calls (tests/golden/gen_series.mjs)
+    and the single-position entry points."""
+    for name, c in _series_cases().items():
+        if "positions" not in c:
+            continue
+        x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+        st = wam.lufs_series(x, c["sr"], c["positions"], momentary=False)
+        mo = wam.lufs_series(x, c["sr"], c["positions"], momentary=True)
+        for k, pos in enumerate(c["positions"]):
+            _close(st[k], G.num(c["short_term"][k]), 1e-6)
+            _close(mo[k], G.num(c["momentary"][k]), 1e-9)
+        for k in (0, 3, len(c["positions"]) - 4):
+            _close(st[k], wam.measure_short_term_lufs(x, c["sr"], c["positions"][k]), 1e-12)
+            _close(mo[k], wam.measure_momentary_lufs(x, c["sr"], c["positions"][k]), 1e-12)
+    # more positions than one gather group (256), unsorted, duplicates
+    c = _series_cases()["series_12s_48k"]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    rng = np.random.default_rng(5)
+    pos = np.concatenate([rng.uniform(0, 12.5, 300), [0.0, 0.0, 9.0]])
+    st = wam.lufs_series(x, c["sr"], pos)
+    for k in (0, 17, 299, 300, 301, 302):
+        _close(st[k], O.short_term_lufs(x, c["sr"], float(pos[k])), 1e-6)
+    assert len(wam.lufs_series(x, c["sr"], [])) == 0
+    with pytest.raises(wam.WamError):
+        wam.lufs_series(x, c["sr"], [1.0, -0.5])
+
+
+def test_extract_peaks(golden):
+    """8f rank 4: waveform peaks identical to the reference's extractPeaks and to the oracle at full size."""
+    for name, c in _series_cases().items():
+        if "num_peaks" not in c:
+            continue
+        x = G.f32(c["input"]) if c["input"] else O.synth(c["idx"], c["nch"], c["n_synth"], c["sr"], c["opts"])[0][:c["n"]]
+        assert np.array_equal(wam.extract_peaks(x, c["num_peaks"]), G.f32(c["peaks"])), name
+    x = O.synth(3, 1, 8640000, 48000, {"clickAmp": 0.7})[0]
+    assert np.array_equal(wam.extract_peaks(x, 800), O.extract_peaks(x, 800))
+    assert np.array_equal(wam.extract_peaks(x[:777], 1000), np.zeros(1000, np.float32))
+    assert len(wam.extract_peaks(x[:100], 0)) == 0

@@ -200,3 +200,39 @@ def test_pcm16_modes_vs_reference(golden):
         assert bytes(O.wav_header(c["nch"], c["n"], c["sr"], 16)).hex() == c["header_hex"]
     S = golden["stages_hot"]["stages"]
     assert np.array_equal(O.pcm16(G.chans(S["limiter"]["out"]), 0), G.u8(S["pcm16_none"]["out"]))
+
+
+def _series_cases():
+    import json, os
+    with open(os.path.join(G.DATA, "series.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _peaks_input(c):
+    if c["input"]:
+        return G.f32(c["input"])
+    return O.synth(c["idx"], c["nch"], c["n_synth"], c["sr"], c["opts"])[0][:c["n"]]
+
+
+def test_lufs_series_vs_reference():
+    """measureShortTermLUFS / measureMomentaryLUFS on a grid of positions (lufs.js:91-171), the reference run by tests/golden/gen_series.mjs."""
+    for name, c in _series_cases().items():
+        if "positions" not in c:
+            continue
+        x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+        for pos, st, mo in zip(c["positions"], c["short_term"], c["momentary"]):
+            close(O.short_term_lufs(x, c["sr"], pos), G.num(st))
+            close(O.momentary_lufs(x, c["sr"], pos), G.num(mo))
+
+
+def test_extract_peaks_vs_reference():
+    """extractPeaks (waveform.js:164-181): identical values (f32 magnitudes), NaN skipped, tail ignored, n < numPeaks -> zeros."""
+    n = 0
+    for name, c in _series_cases().items():
+        if "num_peaks" not in c:
+            continue
+        assert c["exact_f32"]
+        got = O.extract_peaks(_peaks_input(c), c["num_peaks"])
+        assert np.array_equal(got, G.f32(c["peaks"])), name
+        n += 1
+    assert n == 5

@@ -294,6 +294,70 @@ int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample
   return WAM_OK;
 }
 
+int wam_lufs_series(const float* const* ch, int nch, int64_t n, double sample_rate, const double* positions, int npos, int momentary,
+                    double* lufs) {
+  int rc = check_audio(ch, nch, n); if (rc) return rc;
+  if (npos < 0 || (npos > 0 && (!positions || !lufs)) || !(sample_rate > 0)) { set_error("invalid series arguments"); return WAM_ERR_INVALID; }
+  for (int i = 0; i < npos; i++) if (!(positions[i] >= 0)) { set_error("position %d is negative or NaN", i); return WAM_ERR_INVALID; }
+  if (npos == 0) return WAM_OK;
+  const int64_t win = (int64_t)std::floor(sample_rate * (momentary ? 400 : 3000) / 1000);       // lufs.js:130-133 / :93-96
+  std::vector<int64_t> starts, lens; std::vector<int> where;                                    // windows that are measured at all
+  for (int i = 0; i < npos; i++) {
+    const double sp = std::floor(positions[i] * sample_rate);
+    const int64_t start = sp < 9.0e18 ? (int64_t)sp : INT64_MAX;
+    const int64_t len = start < n ? ((n - start < win ? n : start + win) - start) : 0;
+    if ((double)len < (double)win * 0.5 || len <= 0) { lufs[i] = -INFINITY; continue; }          // :98-100 / :135-137
+    starts.push_back(start); lens.push_back(len); where.push_back(i);
+  }
+  const int nw = (int)where.size();
+  if (nw == 0) return WAM_OK;
+  rc = ensure_device(); if (rc) return rc;
+  DevBuf in, idx;
+  rc = upload(ch, nch, n, in, nullptr); if (rc) return rc;
+  rc = idx.alloc(sizeof(int64_t) * 2 * (size_t)nw); if (rc) return rc;
+  int64_t* starts_dev = idx.as<int64_t>(); int64_t* lens_dev = starts_dev + nw;
+  WAM_HIP(hipMemcpyAsync(starts_dev, starts.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, nullptr));
+  WAM_HIP(hipMemcpyAsync(lens_dev, lens.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, nullptr));
+  if (momentary) {
+    DevBuf sums;
+    rc = sums.alloc(sizeof(double) * (size_t)nw * nch); if (rc) return rc;
+    rc = enqueue_momentary_series(in.as<float>(), nch, n, starts_dev, lens_dev, nw, sample_rate, sums.as<double>(), nullptr); if (rc) return rc;
+    std::vector<double> hs((size_t)nw * nch);
+    WAM_HIP(hipMemcpy(hs.data(), sums.p, sizeof(double) * hs.size(), hipMemcpyDeviceToHost));
+    for (int w = 0; w < nw; w++) {
+      double ss = 0;
+      for (int c = 0; c < nch; c++) ss += hs[(size_t)w * nch + c];
+      const double ms = ss / ((double)lens[w] * nch);                                            // :167
+      lufs[where[w]] = ms <= 0 ? -INFINITY : -0.691 + 10 * std::log10(ms);                       // :168-170
+    }
+    return WAM_OK;
+  }
+  // short-term: full windows as batches of "tracks" through the gated meter; the few clipped by the end one by one.
+  // Full windows come first in a stable partition so that their device start indices are contiguous.
+  std::vector<int> full, part;
+  for (int w = 0; w < nw; w++) (lens[w] == win ? full : part).push_back(w);
+  const int kGroup = 256;
+  DevBuf batch;
+  rc = batch.alloc(sizeof(float) * (size_t)nch * (size_t)win * (size_t)(full.empty() ? 1 : (full.size() < (size_t)kGroup ? full.size() : (size_t)kGroup)));
+  if (rc) return rc;
+  std::vector<int64_t> gs; std::vector<double> out;
+  for (size_t g0 = 0; g0 < full.size(); g0 += kGroup) {
+    const int g = (int)(full.size() - g0 < (size_t)kGroup ? full.size() - g0 : (size_t)kGroup);
+    gs.resize(g); out.resize(g);
+    for (int k = 0; k < g; k++) gs[k] = starts[full[g0 + k]];
+    WAM_HIP(hipMemcpy(starts_dev, gs.data(), sizeof(int64_t) * g, hipMemcpyHostToDevice));      // synchronous: gs is reused
+    rc = enqueue_gather_windows(in.as<float>(), nch, n, starts_dev, g, win, batch.as<float>(), nullptr); if (rc) return rc;
+    rc = meter_dev(batch.as<float>(), g, nch, win, sample_rate, -14.0, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;   // :118
+    for (int k = 0; k < g; k++) lufs[where[full[g0 + k]]] = out[k];
+  }
+  for (int w : part) {
+    WAM_HIP(hipMemcpy(starts_dev, &starts[w], sizeof(int64_t), hipMemcpyHostToDevice));
+    rc = enqueue_gather_windows(in.as<float>(), nch, n, starts_dev, 1, lens[w], batch.as<float>(), nullptr); if (rc) return rc;
+    rc = meter_dev(batch.as<float>(), 1, nch, lens[w], sample_rate, -14.0, &lufs[where[w]], nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
+  }
+  return WAM_OK;
+}
+
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate, double fallback,
                         double* lufs, double* dbtp, void* stream) {
   if (!in_dev || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }

@@ -3,6 +3,7 @@
 //   wam_normalize     normalizeChannelsToLUFS (NORMALIZE message)    web/workers/dsp-worker.js:457-527
 //   wam_encode_pcm24  encodeWAV 24-bit sample loop                   web/ui/encoder.js:92-124
 //   wam_wav_header    encodeWAV header                               web/ui/encoder.js:74-86
+//   wam_extract_peaks extractPeaks                                   web/ui/waveform.js:164-181
 //   wam_stft_db       Spectrogram.process / fft / updateLatestColumn web/ui/spectrogram.js:113-257, batched over frames
 #include "chain.hpp"
 #include <cmath>
@@ -42,6 +43,20 @@ __global__ __launch_bounds__(256) void k_dc_sub(const float* __restrict__ in, fl
     const float v = in[chan * n + i];
     out[chan * n + i] = sub ? f32r((double)v - d) : v;
   }
+}
+
+// ------------------------------------------------------------------ waveform peaks
+// extractPeaks (web/ui/waveform.js:164-181): max |x| over num_peaks windows of floor(n / num_peaks) samples of channel 0;
+// NaN never wins the `abs > max` comparison, the tail beyond num_peaks windows is not looked at.  One workgroup per window.
+__global__ __launch_bounds__(256) void k_peaks(const float* __restrict__ x, int64_t per, float* __restrict__ peaks) {
+  __shared__ float red[4];
+  const int64_t st = (int64_t)blockIdx.x * per;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) { const float a = fabsf(x[st + i]); if (a > m) m = a; }
+  for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_down(m, off); if (o > m) m = o; }
+  if (lane_id() == 0) red[wave_id()] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) peaks[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // ------------------------------------------------------------------ 24-bit PCM
@@ -333,6 +348,23 @@ int wam_dc_offset(const float* const* ch, int nch, int64_t n, double* dc, int re
     for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpyAsync(out[c], o.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, nullptr));
   }
   WAM_HIP(hipMemcpyAsync(dc, dcd.p, sizeof(double) * nch, hipMemcpyDeviceToHost, nullptr));
+  WAM_HIP(hipStreamSynchronize(nullptr));
+  return WAM_OK;
+}
+
+int wam_extract_peaks(const float* ch0, int64_t n, int num_peaks, float* peaks) {
+  if (n < 0 || num_peaks < 0 || (n > 0 && !ch0) || (num_peaks > 0 && !peaks)) { set_error("invalid peak arguments"); return WAM_ERR_INVALID; }
+  if (num_peaks == 0) return WAM_OK;
+  const int64_t per = n / num_peaks;                                   // waveform.js:166
+  if (per == 0) { std::memset(peaks, 0, sizeof(float) * (size_t)num_peaks); return WAM_OK; }   // empty windows: max stays 0
+  int rc = ensure_device(); if (rc) return rc;
+  DevBuf in, pk;
+  const int64_t used = per * num_peaks;
+  rc = in.alloc(sizeof(float) * (size_t)used); if (rc) return rc;
+  rc = pk.alloc(sizeof(float) * (size_t)num_peaks); if (rc) return rc;
+  WAM_HIP(hipMemcpyAsync(in.p, ch0, sizeof(float) * (size_t)used, hipMemcpyHostToDevice, nullptr));
+  WAM_LAUNCH("k_peaks", k_peaks, dim3((unsigned)num_peaks), dim3(256), nullptr, (const float*)in.as<float>(), per, pk.as<float>());
+  WAM_HIP(hipMemcpyAsync(peaks, pk.p, sizeof(float) * (size_t)num_peaks, hipMemcpyDeviceToHost, nullptr));
   WAM_HIP(hipStreamSynchronize(nullptr));
   return WAM_OK;
 }

@@ -96,6 +96,38 @@ __global__ void k_momentary(const float* __restrict__ in, int nch, int64_t len, 
   sums[c] = ss;
 }
 
+// The same walk for many windows of one device-resident track (wam_lufs_series): thread (w, c) takes window w of channel c.
+__global__ void k_momentary_series(const float* __restrict__ in, int nch, int64_t n, const int64_t* __restrict__ starts,
+                                   const int64_t* __restrict__ lens, int nwin, MomentaryCoef q, double* __restrict__ sums) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nwin * nch) return;
+  const int w = id / nch, c = id - w * nch;
+  const float* x = in + (int64_t)c * n + starts[w];
+  const int64_t len = lens[w];
+  double x1 = 0, x2 = 0, y1 = 0, y2 = 0, u1 = 0, u2 = 0, v1 = 0, v2 = 0, ss = 0;
+  for (int64_t i = 0; i < len; i++) {
+    const double xi = x[i];
+    const double y = q.s[0] * xi + q.s[1] * x1 + q.s[2] * x2 - q.s[3] * y1 - q.s[4] * y2;
+    x2 = x1; x1 = xi; y2 = y1; y1 = y;
+    const double ui = (double)f32r(y);
+    const double v = q.h[0] * ui + q.h[1] * u1 + q.h[2] * u2 - q.h[3] * v1 - q.h[4] * v2;
+    u2 = u1; u1 = ui; v2 = v1; v1 = v;
+    const double z = (double)f32r(v);
+    ss += z * z;
+  }
+  sums[id] = ss;
+}
+
+// Copies windows [starts[w], starts[w] + len) of every channel of one track [nch][n] into a batch [nwin][nch][len], so that
+// each window is metered like a buffer of its own (measureShortTermLUFS slices the channels, lufs.js:102-116).
+__global__ void k_gather_windows(const float* __restrict__ in, int nch, int64_t n, const int64_t* __restrict__ starts, int64_t len,
+                                 float* __restrict__ out) {
+  const int wc = blockIdx.y, w = wc / nch, c = wc - w * nch;
+  const float* x = in + (int64_t)c * n + starts[w];
+  float* o = out + (int64_t)wc * len;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) o[i] = x[i];
+}
+
 // Stage-8 gain per track from the gated loudness (normalizer.js:39-51).  gains[t] = 1 when
 // the loudness is not finite (silence: the reference returns its input) or normalisation is off.
 __global__ void k_norm_gain(const GateOut* __restrict__ gate, const MeterPlan* __restrict__ plan, int ntracks, double target,
@@ -243,6 +275,20 @@ int enqueue_momentary(const float* in_dev, int nch, int64_t len, double sr, doub
   const Biquad sh = k_high_shelf(sr, 1681.97, 4.0, 0.71), hp = rbj_pass(sr, 38.14, 0.5, true);   // constants.js:7-13
   MomentaryCoef q = { { sh.b0, sh.b1, sh.b2, sh.a1, sh.a2 }, { hp.b0, hp.b1, hp.b2, hp.a1, hp.a2 } };
   WAM_LAUNCH("k_momentary", k_momentary, dim3(1), dim3(64), stream, in_dev, nch, len, q, sums_dev);
+  return WAM_OK;
+}
+
+int enqueue_momentary_series(const float* in_dev, int nch, int64_t n, const int64_t* starts_dev, const int64_t* lens_dev, int nwin, double sr,
+                             double* sums_dev, hipStream_t stream) {
+  const Biquad sh = k_high_shelf(sr, 1681.97, 4.0, 0.71), hp = rbj_pass(sr, 38.14, 0.5, true);   // constants.js:7-13
+  MomentaryCoef q = { { sh.b0, sh.b1, sh.b2, sh.a1, sh.a2 }, { hp.b0, hp.b1, hp.b2, hp.a1, hp.a2 } };
+  WAM_LAUNCH("k_momentary_series", k_momentary_series, dim3((nwin * nch + 63) / 64), dim3(64), stream, in_dev, nch, n, starts_dev, lens_dev, nwin, q, sums_dev);
+  return WAM_OK;
+}
+
+int enqueue_gather_windows(const float* in_dev, int nch, int64_t n, const int64_t* starts_dev, int nwin, int64_t len, float* out_dev, hipStream_t stream) {
+  int64_t bx = (len + 1023) / 1024; if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+  WAM_LAUNCH("k_gather_windows", k_gather_windows, dim3((unsigned)bx, nwin * nch), dim3(256), stream, in_dev, nch, n, starts_dev, len, out_dev);
   return WAM_OK;
 }
 

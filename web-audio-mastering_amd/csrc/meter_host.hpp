@@ -31,6 +31,10 @@ int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t
 int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_t n, const double* gains, const MeterPlan& pl,
                        const MeterScratch& s, hipStream_t stream);
 int enqueue_momentary(const float* in_dev, int nch, int64_t len, double sr, double* sums_dev, hipStream_t stream);
+// many windows of one device-resident track [nch][n]: ungated K-weighted sums per (window, channel) / window copies as a batch
+int enqueue_momentary_series(const float* in_dev, int nch, int64_t n, const int64_t* starts_dev, const int64_t* lens_dev, int nwin, double sr,
+                             double* sums_dev, hipStream_t stream);
+int enqueue_gather_windows(const float* in_dev, int nch, int64_t n, const int64_t* starts_dev, int nwin, int64_t len, float* out_dev, hipStream_t stream);
 int enqueue_norm_gain(const MeterScratch& s, int ntracks, double target, double* gains, double* lufs_in, hipStream_t stream);
 int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream);
 double finish_lufs(const MeterPlan& pl, const GateOut& g);

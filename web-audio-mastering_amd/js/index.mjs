@@ -60,6 +60,13 @@ export function measureShortTermLUFS(audioBuffer, position = 0) {               
 export function measureMomentaryLUFS(audioBuffer, position = 0) {                    // lufs.js:128
   return addon().windowLufsSync(chansOf(audioBuffer), audioBuffer.sampleRate, position, true);
 }
+// the two window measures at many positions in one call (one upload); no counterpart by name in the reference, which polls per position
+export function measureLUFSSeries(audioBuffer, positions, kind = 'short-term') {
+  return Array.from(addon().lufsSeries(chansOf(audioBuffer), audioBuffer.sampleRate, Float64Array.from(positions), kind === 'momentary'));
+}
+export function extractPeaks(audioBuffer, numPeaks = 800) {                          // ui/waveform.js:164 (channel 0, plain number[])
+  return Array.from(addon().extractPeaks([audioBuffer.getChannelData(0)], numPeaks));
+}
 export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
   return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
 }

@@ -341,6 +341,32 @@ napi_value dc_offset(napi_env env, napi_callback_info info) {        // (channel
   if (remove) napi_set_named_property(env, o, "channels", make_channels(env, out));
   return o;
 }
+napi_value extract_peaks(napi_env env, napi_callback_info info) {    // (channels, numPeaks) -> Float32Array   (waveform.js:164-181, channel 0)
+  napi_value a[2]; size_t argc = 2; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  int32_t np = 800; if (argc >= 2) napi_get_value_int32(env, a[1], &np);
+  if (np < 0) np = 0;
+  void* data; napi_value ab, ta; NAPI_CALL(env, napi_create_arraybuffer(env, sizeof(float) * (size_t)np, &data, &ab));
+  auto p = in.ptrs();
+  if (wam_extract_peaks(p[0], in.n, np, (float*)data)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  NAPI_CALL(env, napi_create_typedarray(env, napi_float32_array, (size_t)np, ab, 0, &ta));
+  return ta;
+}
+napi_value lufs_series(napi_env env, napi_callback_info info) {      // (channels, sampleRate, positions: Float64Array, momentary) -> Float64Array
+  napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  double sr = 0; napi_get_value_double(env, a[1], &sr);
+  napi_typedarray_type tt; size_t count = 0; void* pos = nullptr; napi_value pab; size_t off;
+  if (argc < 3 || napi_get_typedarray_info(env, a[2], &tt, &count, &pos, &pab, &off) != napi_ok || tt != napi_float64_array) {
+    napi_throw_type_error(env, nullptr, "positions must be a Float64Array"); return nullptr;
+  }
+  bool mom = false; if (argc >= 4) { napi_value b; if (napi_coerce_to_bool(env, a[3], &b) == napi_ok) napi_get_value_bool(env, b, &mom); }
+  void* data; napi_value ab, ta; NAPI_CALL(env, napi_create_arraybuffer(env, sizeof(double) * count, &data, &ab));
+  auto p = in.ptrs();
+  if (wam_lufs_series(p.data(), (int)p.size(), in.n, sr, (const double*)pos, (int)count, mom ? 1 : 0, (double*)data)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  NAPI_CALL(env, napi_create_typedarray(env, napi_float64_array, count, ab, 0, &ta));
+  return ta;
+}
 napi_value init_dev(napi_env env, napi_callback_info info) {
   napi_value a[1]; size_t argc = 1; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
   int32_t dev = 0; if (argc >= 1) napi_get_value_int32(env, a[0], &dev);
@@ -366,6 +392,8 @@ napi_value Init(napi_env env, napi_value exports) {
     {"encodePcm16", nullptr, encode_pcm16, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stftDb", nullptr, stft_db, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"dcOffset", nullptr, dc_offset, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"extractPeaks", nullptr, extract_peaks, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"lufsSeries", nullptr, lufs_series, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

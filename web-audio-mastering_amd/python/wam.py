@@ -154,6 +154,25 @@ def measure_momentary_lufs(chans, sr, position=0.0):
     return out.value
 
 
+def lufs_series(chans, sr, positions, momentary=False):
+    """measureShortTermLUFS / measureMomentaryLUFS (web/lib/dsp/lufs.js:91,128) at many positions, one upload"""
+    pin, keep = _ptrs(chans)
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    out = np.zeros(len(pos), dtype=np.float64)
+    DP = C.POINTER(C.c_double)
+    _check(lib().wam_lufs_series(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), pos.ctypes.data_as(DP), C.c_int(len(pos)),
+                                 C.c_int(1 if momentary else 0), out.ctypes.data_as(DP)))
+    return out
+
+
+def extract_peaks(ch0, num_peaks=800):
+    """extractPeaks(audioBuffer, numPeaks) - web/ui/waveform.js:164 (channel 0 only)"""
+    x = np.ascontiguousarray(ch0, dtype=np.float32)
+    out = np.zeros(max(num_peaks, 0), dtype=np.float32)
+    _check(lib().wam_extract_peaks(x.ctypes.data_as(FP), C.c_int64(len(x)), C.c_int(num_peaks), out.ctypes.data_as(FP)))
+    return out
+
+
 def find_true_peak(chans):
     """findTruePeak(audioBuffer) - web/lib/dsp/true-peak.js:46"""
     pin, keep = _ptrs(chans)
