@@ -33,12 +33,22 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2
 // ---- the transform ------------------------------------------------------------------------------------
 // A 2048-point real frame is transformed as a 1024-point complex FFT of z[m] = x[2m] + i x[2m+1] plus an O(N)
 // split step (and the mirror image of that for the inverse), which halves the butterfly work and LDS traffic.
-// The 1024-point FFT is a radix-4 Stockham autosort (natural order in and out, no bit reversal): 256 threads, one
-// butterfly per thread and pass, five passes.  Every pass reads z[g + 256 r] (unit stride across lanes) and
-// writes 4 (g - j) + j + r Ls; the array is padded by 4 entries every 16 so that those strided writes spread over
-// the LDS banks.  Tables: twA[k] = exp(-2 pi i k / 1024), k < 768; twB[k] = exp(-2 pi i k / 2048), k <= 512.
-constexpr int kM = 1024, kZ = kM + kM / 4, kTwA = 768, kTwB = 513;
-__device__ __forceinline__ int padz(int i) { return i + ((i >> 4) << 2); }
+//
+// One WAVEFRONT transforms one frame: 1024 = 16 x 16 x 4, sixteen points per lane.
+//   1. lane l holds z[64 r + l], r = 0..15: a 16-point DFT over r in registers            -> A[k1], k1 = 0..15
+//   2. twiddle A[k1] *= W1024^(l k1)   (per-lane constants, kept in registers for the whole kernel)
+//   3. one exchange through LDS (rows of k1, 64 + 4 columns): lane (k1' = lane >> 2, q = lane & 3) takes
+//      A'[k1'][q + 4 m], m = 0..15
+//   4. a second 16-point DFT over m in registers                                            -> B[j1]
+//   5. twiddle B[j1] *= W64^(q j1)
+//   6. a radix-4 butterfly across the four lanes of a quad (DPP quad_perm moves, no LDS): lane (k1', q) ends up with
+//      Z[k1' + 16 j1 + 256 rev2(q)], j1 = 0..15.
+// That is 2 LDS round trips per transform instead of the 5 of a radix-4 pass structure over 256 threads, and the only
+// synchronisation inside a transform is the one between the exchange's writes and reads.  The four wavefronts of a
+// workgroup transform four consecutive frames at the same time.
+constexpr int kM = 1024, kTw1 = 1024, kTwB = 513;    // tables: W1024^k, k < 1024; W2048^k, k <= 512
+constexpr int kExRow = 68;                           // exchange row stride (float2): 16 rows land on distinct banks
+constexpr int kWaveBuf = 16 * kExRow;                // float2 per wavefront buffer (>= 1024)
 
 template <bool INV>
 __device__ __forceinline__ void r4_butterfly(float2 a[4]) {
@@ -55,34 +65,93 @@ __device__ __forceinline__ void r4_butterfly(float2 a[4]) {
   }
 }
 
-// a[r] = input element g + 256 r (in registers).  Passes alternate between two LDS arrays (one barrier per pass):
-// pass 0 writes z0, then z0 -> z1 -> z0 -> z1 -> z0; the result (padded, natural order) is in z0 and visible after the
-// final barrier.  Unnormalised in both directions.  The caller guarantees that nobody still reads z0 or z1 on entry.
+// a * W16^P (forward) or a * conj(W16^P) (inverse), P a compile-time constant
+template <bool INV, int P>
+__device__ __forceinline__ float2 mul_w16(float2 a) {
+  constexpr float h = 0.70710678118654752f, c = 0.92387953251128674f, s = 0.38268343236508977f;
+  if (P == 0) return a;
+  if (P == 4) return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+  if (P == 2) return INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
+  if (P == 6) return INV ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y));
+  // W16^1 = (c, -s), W16^3 = (s, -c), W16^9 = (-c, s)
+  const float wr = P == 1 ? c : (P == 3 ? s : -c), wi = P == 1 ? -s : (P == 3 ? -c : s);
+  return INV ? cmulc(a, make_float2(wr, wi)) : cmul(a, make_float2(wr, wi));
+}
+
+// 16-point DFT in registers, natural order in and out: index r = r0 + 4 r1 in, k = ka + 4 kb out;
+// W16^(r k) = W16^(r0 ka) W4^(r0 kb) W4^(r1 ka).
 template <bool INV>
-__device__ __forceinline__ void fft1024(float2 a[4], float2* z0, float2* z1, const float2* twA) {
-  const int g = threadIdx.x;
-  r4_butterfly<INV>(a);
+__device__ __forceinline__ void dft16(float2 v[16]) {
+  float2 T[4][4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) z0[padz(4 * g + r)] = a[r];
-  __syncthreads();
-#pragma unroll
-  for (int s = 1; s < 5; s++) {
-    const int Ls = 1 << (2 * s), shift = 8 - 2 * s;
-    const float2* src = (s & 1) ? z0 : z1;
-    float2* dst = (s & 1) ? z1 : z0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) a[r] = src[padz(g + 256 * r)];
-    const int j = g & (Ls - 1);
-#pragma unroll
-    for (int r = 1; r < 4; r++) {
-      const float2 w = twA[(r * j) << shift];
-      a[r] = INV ? cmulc(a[r], w) : cmul(a[r], w);
-    }
+  for (int r0 = 0; r0 < 4; r0++) {
+    float2 a[4] = { v[r0], v[r0 + 4], v[r0 + 8], v[r0 + 12] };
     r4_butterfly<INV>(a);
-    const int base = ((g - j) << 2) + j;
 #pragma unroll
-    for (int r = 0; r < 4; r++) dst[padz(base + r * Ls)] = a[r];
-    __syncthreads();
+    for (int ka = 0; ka < 4; ka++) T[r0][ka] = a[ka];
+  }
+  T[1][1] = mul_w16<INV, 1>(T[1][1]); T[1][2] = mul_w16<INV, 2>(T[1][2]); T[1][3] = mul_w16<INV, 3>(T[1][3]);
+  T[2][1] = mul_w16<INV, 2>(T[2][1]); T[2][2] = mul_w16<INV, 4>(T[2][2]); T[2][3] = mul_w16<INV, 6>(T[2][3]);
+  T[3][1] = mul_w16<INV, 3>(T[3][1]); T[3][2] = mul_w16<INV, 6>(T[3][2]); T[3][3] = mul_w16<INV, 9>(T[3][3]);
+#pragma unroll
+  for (int ka = 0; ka < 4; ka++) {
+    float2 b[4] = { T[0][ka], T[1][ka], T[2][ka], T[3][ka] };
+    r4_butterfly<INV>(b);
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) v[ka + 4 * kb] = b[kb];
+  }
+}
+
+// value of lane ^ 2 / lane ^ 1 within each quad (DPP quad_perm [2,3,0,1] = 0x4E, [1,0,3,2] = 0xB1)
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+
+// Twiddles live in LDS: twl[64 (k - 1) + lane] = W1024^(lane k), k = 1..15 (unit stride across lanes), and
+// twq[16 q + k] = W64^(q k) (lanes of equal q read the same word: a broadcast).  Keeping the 15 per-lane values in
+// registers instead costs 30 VGPRs and with them a wavefront of occupancy.
+constexpr int kTwl = 15 * 64, kTwq = 64;
+struct WaveTw { const float2* l; const float2* q; };
+__device__ __forceinline__ void load_wave_tw(const float2* __restrict__ tw1, WaveTw& T, float2* tws) {
+  for (int i = threadIdx.x; i < kTwl; i += 256) tws[i] = tw1[(i & 63) * ((i >> 6) + 1)];
+  if (threadIdx.x < 64) tws[kTwl + threadIdx.x] = tw1[16 * (threadIdx.x >> 4) * (threadIdx.x & 15)];
+  T.l = tws; T.q = tws + kTwl;
+}
+// output slot of this lane's j1-th result: k1' + 16 j1 + 256 rev2(q)
+__device__ __forceinline__ int wave_out_base() { const int lane = lane_id(), q = lane & 3; return (lane >> 2) + 256 * (((q & 1) << 1) | (q >> 1)); }
+
+// v[r] = z[64 r + lane] on entry; on return v[j1] = Z[wave_out_base() + 16 j1].  `ex` = this wavefront's LDS buffer
+// (kWaveBuf float2); contains a workgroup barrier (all four wavefronts transform in step).  Unnormalised both ways.
+// Orders this wavefront's LDS writes before its later LDS reads (other lanes' data) without a workgroup barrier: the
+// LDS unit executes one wavefront's instructions in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft1024_wave(float2 v[16], float2* ex, const WaveTw& T) {
+  const int lane = lane_id(), q = lane & 3;
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; k++) { const float2 w = T.l[64 * (k - 1) + lane]; v[k] = INV ? cmulc(v[k], w) : cmul(v[k], w); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) ex[k * kExRow + lane] = v[k];
+  wave_sync();
+  const float2* row = ex + (lane >> 2) * kExRow + q;
+#pragma unroll
+  for (int m = 0; m < 16; m++) v[m] = row[4 * m];
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; k++) { const float2 w = T.q[16 * q + k]; v[k] = INV ? cmulc(v[k], w) : cmul(v[k], w); }
+  // radix-4 across the quad: lanes 0,1 get the sums (v0 + v2, v1 + v3), lanes 2,3 the differences; lane 3 turns its
+  // difference by -i (forward) / +i (inverse); then even lanes add, odd lanes subtract: lane q holds output rev2(q)
+  const float sg1 = (q & 2) ? -1.0f : 1.0f, sg2 = (q & 1) ? -1.0f : 1.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    float2 a = make_float2(fmaf(sg1, v[k].x, quad_xor2(v[k].x)), fmaf(sg1, v[k].y, quad_xor2(v[k].y)));
+    if (q == 3) a = INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    v[k] = make_float2(fmaf(sg2, a.x, quad_xor1(a.x)), fmaf(sg2, a.y, quad_xor1(a.y)));
   }
 }
 
@@ -98,78 +167,112 @@ __device__ __forceinline__ BinPair split_pair(float2 zk, float2 zm, float2 w) {
   return p;
 }
 
-// Band RMS of every frame.  grid = (frame groups, channels); each workgroup handles frames f = blockIdx.x, += gridDim.x.
+// windowed analysis frame of this lane: v[r] = (x[pos + 2 m] w[2 m], x[pos + 2 m + 1] w[2 m + 1]), m = 64 r + lane (fft.js:43-45)
+__device__ __forceinline__ void load_frame(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, float2 v[16]) {
+  const int lane = lane_id();
+  const float* xp = x + pos + 2 * lane;
+  const float2* wp = (const float2*)win + lane;                    // the window table is 8-byte aligned, 2 m is even
+  if (((uintptr_t)xp & 7) == 0) {                                  // uniform: pos is even, so this is the alignment of x
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = *(const float2*)(xp + 128 * r);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = make_float2(xp[128 * r], xp[128 * r + 1]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    float v0 = v[r].x, v1 = v[r].y;
+    if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
+    if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
+    if (!(v1 == v1)) v1 = 0.0f;
+    const float2 w = wp[64 * r];
+    v[r] = make_float2(v0 * w.x, v1 * w.y);                        // one f32 rounding of the exact product, as f32(double product)
+  }
+}
+
+// Band RMS of every frame.  grid = (frame groups, channels); wavefront w of a workgroup takes frame 4 g + w of its groups
+// g = blockIdx.x, += gridDim.x; lane l then holds the bin pairs (k, 1024 - k), k = l + 64 j, j = 0..7.
 __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                   const float2* __restrict__ twg, const float* __restrict__ wing,
                                                   float* __restrict__ band_rms, double pre_gain) {
-  __shared__ float2 z[kZ], zb[kZ];
-  __shared__ float2 tw[kTwA + kTwB];
-  __shared__ float part[4][kBands];
+  __shared__ float2 buf[4][kWaveBuf];
+  __shared__ float2 tws[kTwl + kTwq];
+  __shared__ float bacc[4][8 * 64];
   const DeharshPlan& P = *dp;
-  const float2* twA = tw; const float2* twB = tw + kTwA;
-  const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
+  const float2* __restrict__ twB = twg + kTw1;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
-  const int t = threadIdx.x;
-  for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
-  // bins of this thread: pairs k1 = t (t = 0: DC, and bin 512 in the second slot) and k2 = t + 256
-  const int k1 = t, k2 = t + 256;
-  const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
+  const int lane = lane_id(), wave = wave_id();
+  float2* z = buf[wave];
+  float* ba = bacc[wave];
+#pragma unroll
+  for (int b = 0; b < 8; b++) ba[b * 64 + lane] = 0.0f;
+  WaveTw T; load_wave_tw(twg, T, tws);
   __syncthreads();
-  for (int64_t f = blockIdx.x; f < P.nframes; f += gridDim.x) {
-    const int64_t pos = f * kHop;
-    float2 a[4];
+  const int ob = wave_out_base();
+  uint64_t bands = 0;                           // 3 bits per bin: bins k = lane + 64 j at 3 j, bins 1024 - k at 24 + 3 j
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = 2 * (t + 256 * r);
-      float v0 = x[pos + i], v1 = x[pos + i + 1];
-      if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
-      if (!(v0 == v0)) v0 = 0.0f;                                  // (input[i] || 0)
-      if (!(v1 == v1)) v1 = 0.0f;
-      a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));   // fft.js:43-45
+  for (int j = 0; j < 8; j++) {
+    const int k = lane + 64 * j;
+    bands |= (uint64_t)P.band_of[k] << (3 * j) | (uint64_t)P.band_of[k == 0 ? 512 : kM - k] << (24 + 3 * j);
+  }
+  const int64_t ngroups = (P.nframes + 3) / 4;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t f = 4 * g + wave;
+    if (f >= P.nframes) break;                                     // wavefronts are independent here: no workgroup barriers below
+    float2 v[16];
+    load_frame(x, f * kHop, wing, pre_gain, v);
+    wave_sync();                                                   // the previous frame's reads of z precede the writes below
+    fft1024_wave<false>(v, z, T);
+#pragma unroll
+    for (int j = 0; j < 16; j++) z[ob + 16 * j] = v[j];
+    wave_sync();
+    // band sums: every lane adds its 16 squared magnitudes into its own column of a [band][lane] LDS array (no
+    // contention, no selects), then the 8 rows are reduced across the wavefront by a halving butterfly (10 exchanges
+    // instead of 7 x 6): lane L ends up with the total of band 4 (L & 1) + 2 (L >> 1 & 1) + (L >> 2 & 1).
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = lane + 64 * j;
+      float m2k, m2m;                                              // |X|^2 of bins k and 1024 - k (k = 0: DC and bin 512)
+      if (k == 0) {
+        const float2 z0 = z[0], zh = z[512];
+        const float x0 = z0.x + z0.y;
+        m2k = x0 * x0; m2m = zh.x * zh.x + zh.y * zh.y;
+      } else {
+        const BinPair p = split_pair(z[k], z[kM - k], twB[k]);
+        const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xm = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+        m2k = xk.x * xk.x + xk.y * xk.y; m2m = xm.x * xm.x + xm.y * xm.y;
+      }
+      const float mk = sqrtf(m2k), mm = sqrtf(m2m);                // the reference squares the f32 magnitude (:335-337, :456-460)
+      const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;
+      ba[bk * 64 + lane] += mk * mk;
+      ba[bm * 64 + lane] += mm * mm;
     }
-    fft1024<false>(a, z, zb, twA);
-    float m2[4];                                                   // |X|^2 of the four bins (dynamic-processor.js:456-460)
+    float r8[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) { r8[b] = ba[b * 64 + lane]; ba[b * 64 + lane] = 0.0f; }
+    float r4[4], r2[2], r1;
     {
-      const float2 zk = z[padz(k2)], zm = z[padz(kM - k2)];
-      const BinPair p = split_pair(zk, zm, twB[k2]);
-      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xm = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
-      m2[2] = xk.x * xk.x + xk.y * xk.y; m2[3] = xm.x * xm.x + xm.y * xm.y;
-    }
-    if (t == 0) {
-      const float2 z0 = z[padz(0)], zh = z[padz(512)];
-      const float x0 = z0.x + z0.y;
-      m2[0] = x0 * x0; m2[1] = zh.x * zh.x + zh.y * zh.y;
-    } else {
-      const float2 zk = z[padz(k1)], zm = z[padz(kM - k1)];
-      const BinPair p = split_pair(zk, zm, twB[k1]);
-      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xm = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
-      m2[0] = xk.x * xk.x + xk.y * xk.y; m2[1] = xm.x * xm.x + xm.y * xm.y;
-    }
-    float be[kBands];
+      const bool hi = lane & 1;
 #pragma unroll
-    for (int b = 0; b < kBands; b++) be[b] = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float mag = sqrtf(m2[q]);                              // the reference squares the f32 magnitude (:335-337)
-#pragma unroll
-      for (int b = 0; b < kBands; b++) if (b == bnd[q]) be[b] += mag * mag;
+      for (int i = 0; i < 4; i++) { const float send = hi ? r8[i] : r8[i + 4], keep = hi ? r8[i + 4] : r8[i]; r4[i] = keep + __shfl_xor(send, 1); }
     }
+    {
+      const bool hi = lane & 2;
 #pragma unroll
-    for (int b = 0; b < kBands; b++) {
-      float v = be[b];
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-      if (lane_id() == 0) part[wave_id()][b] = v;
+      for (int i = 0; i < 2; i++) { const float send = hi ? r4[i] : r4[i + 2], keep = hi ? r4[i + 2] : r4[i]; r2[i] = keep + __shfl_xor(send, 2); }
     }
-    __syncthreads();
-    if (t < kBands) {
-      const float s = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
-      const float rms = P.cnt[t] > 0 ? f32r(sqrt((double)s / (double)P.cnt[t])) : s;     // :335-339
-      band_rms[(chan * P.nframes + f) * kBands + t] = rms;
+    {
+      const bool hi = lane & 4;
+      const float send = hi ? r2[0] : r2[1], keep = hi ? r2[1] : r2[0];
+      r1 = keep + __shfl_xor(send, 4);
     }
-    // the next frame's first write to z / part comes after this frame's reads: fft1024 writes z only after all threads
-    // passed the barrier above, and part is rewritten after the barriers inside fft1024
+    r1 += __shfl_xor(r1, 8); r1 += __shfl_xor(r1, 16); r1 += __shfl_xor(r1, 32);
+    const int band = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+    if (lane < 8 && band < kBands) {
+      const float rms = P.cnt[band] > 0 ? f32r(sqrt((double)r1 / (double)P.cnt[band])) : r1;   // :335-339
+      band_rms[(chan * P.nframes + f) * kBands + band] = rms;
+    }
   }
 }
 
@@ -220,24 +323,30 @@ __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict_
 // (avg' = 0.3 mag + 0.7 avg) and the overlap-add ring; a segment rebuilds both by re-running `warm` frames before
 // f0: the EMA forgets its start value as 0.7^warm, and the ring needs the three frames before f0.  Warm-up frames
 // more than three before f0 skip the inverse transform.
-__global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, float* __restrict__ out, int64_t n,
-                                                  const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
-                                                  const float* __restrict__ wing, const double* __restrict__ band_env, double pre_gain,
-                                                  int64_t seg_frames, int64_t warm) {
-  __shared__ float2 z[kZ], zb[kZ];
-  __shared__ float2 tw[kTwA + kTwB];
-  __shared__ float xin[kN];      // input ring: sample s at xin[s & 2047]
-  __shared__ float ola[kN];      // overlap-add ring
-  __shared__ float bg[kBands];
+//
+// Frames are taken four at a time, one per wavefront, in four phases separated by workgroup barriers:
+//   P1 (per wavefront)  windowed frame -> FFT -> Z in the wavefront's LDS buffer
+//   P2 (per bin)        thread t owns the bin pairs (t, 1024 - t) and (t + 256, 768 - t) with their EMA state in registers
+//                       and walks the four frames IN ORDER: split, resonance, gain, fold back into the same slots
+//   P3 (per wavefront)  inverse FFT, 1/1024, synthesis window -> the frame's 2048 output samples in the buffer
+//   P4 (per ring slot)  thread t owns the overlap-add slots t + 256 j: adds the four frames in order, emits the
+//                       512 samples each frame completes (normalise, 85/15 mix) and clears their slots
+__global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                     const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
+                                                     const float* __restrict__ wing, const double* __restrict__ band_env, double pre_gain,
+                                                     int64_t seg_frames, int64_t warm) {
+  __shared__ float2 buf[4][kWaveBuf];
+  __shared__ float ola[kN];      // overlap-add ring: sample s at ola[s & 2047]
+  __shared__ float2 tws[kTwl + kTwq];
+  __shared__ float bg[2][4][8];  // band gains of the group's four frames, double-buffered by group parity
   const DeharshPlan& P = *dp;
-  const float2* twA = tw; const float2* twB = tw + kTwA;
+  const float2* twB = twg + kTw1;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = lane_id(), wave = wave_id();
   const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423
   const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
-  for (int i = t; i < kTwA + kTwB; i += 256) tw[i] = twg[i];
   for (int i = t; i < kN; i += 256) ola[i] = 0.0f;
   auto load_in = [&](int64_t s) -> float {
     float v = (s < n) ? x[s] : 0.0f;
@@ -249,103 +358,130 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
   int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
   const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
   const bool last_seg = f1 >= F;
-  if (F > 0) for (int i = t; i < kN - kHop; i += 256) { const int64_t s = fs * kHop + i; xin[s & (kN - 1)] = load_in(s); }   // each frame adds 512
-  // bins of this thread: the pairs (k1, 1024 - k1) and (k2, 1024 - k2), k1 = t, k2 = t + 256; thread 0 holds DC and, in
+  WaveTw T; load_wave_tw(twg, T, tws);
+  __syncthreads();
+  const int ob = wave_out_base();
+  float2* zw = buf[wave];
+  // bins of this thread in P2: the pairs (k1, 1024 - k1) and (k2, 1024 - k2), k1 = t, k2 = t + 256; thread 0 holds DC and, in
   // the slot of "1024 - 0", bin 512.  avg[] = the resonance detector's running mean of those four bins.
   const int k1 = t, k2 = t + 256;
   const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
+  const float2 wk1 = twB[k1], wk2 = twB[k2];
   float avg[4] = {0, 0, 0, 0};
-  for (int64_t f = fs; f < f1; f++) {
-    const int64_t pos = f * kHop;
-    const bool synth = f + 3 >= f0;        // this frame's output reaches samples the segment emits
-    __syncthreads();
-    // newest 512 samples of this frame: [pos + 1536, pos + 2048)
-    for (int i = t; i < kHop; i += 256) { const int64_t s = pos + (kN - kHop) + i; xin[s & (kN - 1)] = load_in(s); }
-    if (t < kBands) bg[t] = band_gain_db_of(band_env[(chan * F + f) * kBands + t], P, t);
-    __syncthreads();
-    float2 a[4];
+  int par = 0;
+  for (int64_t g = fs; g < f1; g += 4, par ^= 1) {
+    const int64_t f = g + wave;                // this wavefront's frame
+    const bool valid = f < f1;
+    const bool synth = valid && f + 3 >= f0;   // this frame's output reaches samples the segment emits
+    const bool any_synth = g + 3 + 3 >= f0;    // some frame of the group is synthesised (uniform)
+    float2 v[16];
+    // ---- P1
+    if (valid) load_frame(x, f * kHop, win, pre_gain, v);
+    else {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = 2 * (t + 256 * r);
-      const int o = (int)((pos + i) & (kN - 1));               // pos is even: o + 1 does not wrap
-      float v0 = xin[o], v1 = xin[o + 1];
-      if (!(v0 == v0)) v0 = 0.0f;
-      if (!(v1 == v1)) v1 = 0.0f;
-      a[r] = make_float2(f32r((double)v0 * (double)win[i]), f32r((double)v1 * (double)win[i + 1]));
+      for (int r = 0; r < 16; r++) v[r] = make_float2(0.f, 0.f);
     }
-    fft1024<false>(a, z, zb, twA);
-    // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
-    const bool first = f == fs;            // the detector's first frame (:203-207); a warm start for later segments
-    auto bin_gain = [&](float mag, float& av_state, int band) -> float {
-      float res = 0.0f;
-      if (first) av_state = mag;
-      else {
-        av_state = f32r(0.3 * (double)mag + (1 - 0.3) * (double)av_state);
-        const double av = av_state;
-        if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, ((double)mag / av - 1.5) / 2));
-      }
-      double gdb = bg[band];
-      if (res > 0) gdb += -3.0 * (double)res * 0.2;
-      return exp2f((float)(gdb * 0.16609640474436813));        // 10^(gdb/20), stored as f32 by the reference
-    };
-    // scale the bins (mirror implied, :471-476) and fold the spectrum back into the 1024-point input of the inverse:
-    //   Ye = (Y[k] + conj Y[M-k]) / 2, Yo = (Y[k] - conj Y[M-k]) / 2 conj(W^k), Z'[k] = Ye + i Yo, Z'[M-k] = conj Ye + i conj Yo
-    auto do_pair = [&](int k, float& av_k, float& av_m, int band_k, int band_m) {
-      const float2 zk = z[padz(k)], zm = z[padz(kM - k)];
-      const float2 w = twB[k];
-      const BinPair p = split_pair(zk, zm, w);
-      const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xmc = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
-      const float gk = bin_gain(sqrtf(xk.x * xk.x + xk.y * xk.y), av_k, band_k);
-      const float gm = bin_gain(sqrtf(xmc.x * xmc.x + xmc.y * xmc.y), av_m, band_m);
-      if (!synth) return;
-      const float2 yk = make_float2(xk.x * gk, xk.y * gk), ymc = make_float2(xmc.x * gm, xmc.y * gm);
-      const float2 ye = make_float2(0.5f * (yk.x + ymc.x), 0.5f * (yk.y + ymc.y));
-      const float2 yo = cmulc(make_float2(0.5f * (yk.x - ymc.x), 0.5f * (yk.y - ymc.y)), w);
-      z[padz(k)] = make_float2(ye.x - yo.y, ye.y + yo.x);
-      z[padz(kM - k)] = make_float2(ye.x + yo.y, yo.x - ye.y);
-    };
-    do_pair(k2, avg[2], avg[3], bnd[2], bnd[3]);
-    if (t == 0) {
-      const float2 z0 = z[padz(0)], zh = z[padz(512)];
-      const float x0 = z0.x + z0.y, xny = z0.x - z0.y;          // X[0] and X[1024] are real; the Nyquist bin is not scaled
-      const float g0 = bin_gain(fabsf(x0), avg[0], bnd[0]);
-      const float gh = bin_gain(sqrtf(zh.x * zh.x + zh.y * zh.y), avg[1], bnd[1]);
-      if (synth) {
-        const float y0 = x0 * g0;
-        z[padz(0)] = make_float2(0.5f * (y0 + xny), 0.5f * (y0 - xny));
-        z[padz(512)] = make_float2(zh.x * gh, zh.y * gh);
-      }
-    } else {
-      do_pair(k1, avg[0], avg[1], bnd[0], bnd[1]);
-    }
-    if (!synth) continue;                   // uniform across the workgroup
-    __syncthreads();
+    if (t < 28) { const int w = t / kBands, b = t - w * kBands; if (g + w < f1) bg[par][w][b] = band_gain_db_of(band_env[(chan * F + g + w) * kBands + b], P, b); }
+    __syncthreads();                           // the previous group's P4 reads of the buffers are done
+    fft1024_wave<false>(v, zw, T);
 #pragma unroll
-    for (int r = 0; r < 4; r++) a[r] = z[padz(t + 256 * r)];
-    fft1024<true>(a, zb, z, twA);             // pass 0 writes zb while others may still read z: no barrier in between
-    // synthesis window + overlap-add (fft.js:63-65, dynamic-processor.js:483-487): z[m] = 1024 (y[2m], y[2m+1])
+    for (int j = 0; j < 16; j++) zw[ob + 16 * j] = v[j];
+    __syncthreads();
+    // ---- P2
+    for (int w = 0; w < 4; w++) {
+      const int64_t fw = g + w;
+      if (fw >= f1) break;                     // uniform
+      float2* z = buf[w];
+      const bool syn = fw + 3 >= f0;
+      const bool first = fw == fs;             // the detector's first frame (:203-207); a warm start for later segments
+      // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
+      // (single precision throughout: the spectrum itself is a float32 FFT, the detector's thresholds are continuous)
+      auto bin_gain = [&](float mag, float& av_state, int band) -> float {
+        float gdb = bg[par][w][band];
+        if (first) av_state = mag;
+        else {
+          av_state = fmaf(0.3f, mag, 0.7f * av_state);
+          const float av = av_state;
+          if (av > 1e-10f && mag > av * 1.5f) {
+            const float res = fminf(1.0f, (mag * __builtin_amdgcn_rcpf(av) - 1.5f) * 0.5f);
+            gdb = fmaf(-0.6f, res, gdb);                           // -3 dB * res * 0.2 (:372-376)
+          }
+        }
+        return exp2f(gdb * 0.16609640474436813f);                  // 10^(gdb/20)
+      };
+      // scale the bins (mirror implied, :471-476) and fold the spectrum back into the 1024-point input of the inverse:
+      //   Ye = (Y[k] + conj Y[M-k]) / 2, Yo = (Y[k] - conj Y[M-k]) / 2 conj(W^k), Z'[k] = Ye + i Yo, Z'[M-k] = conj Ye + i conj Yo
+      auto do_pair = [&](int k, float2 wtw, float& av_k, float& av_m, int band_k, int band_m) {
+        const float2 zk = z[k], zm = z[kM - k];
+        const BinPair p = split_pair(zk, zm, wtw);
+        const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xmc = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+        const float gk = bin_gain(sqrtf(xk.x * xk.x + xk.y * xk.y), av_k, band_k);
+        const float gm = bin_gain(sqrtf(xmc.x * xmc.x + xmc.y * xmc.y), av_m, band_m);
+        if (!syn) return;
+        const float2 yk = make_float2(xk.x * gk, xk.y * gk), ymc = make_float2(xmc.x * gm, xmc.y * gm);
+        const float2 ye = make_float2(0.5f * (yk.x + ymc.x), 0.5f * (yk.y + ymc.y));
+        const float2 yo = cmulc(make_float2(0.5f * (yk.x - ymc.x), 0.5f * (yk.y - ymc.y)), wtw);
+        z[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
+        z[kM - k] = make_float2(ye.x + yo.y, yo.x - ye.y);
+      };
+      do_pair(k2, wk2, avg[2], avg[3], bnd[2], bnd[3]);
+      if (t == 0) {
+        const float2 z0 = z[0], zh = z[512];
+        const float x0 = z0.x + z0.y, xny = z0.x - z0.y;        // X[0] and X[1024] are real; the Nyquist bin is not scaled
+        const float g0 = bin_gain(fabsf(x0), avg[0], bnd[0]);
+        const float gh = bin_gain(sqrtf(zh.x * zh.x + zh.y * zh.y), avg[1], bnd[1]);
+        if (syn) {
+          const float y0 = x0 * g0;
+          z[0] = make_float2(0.5f * (y0 + xny), 0.5f * (y0 - xny));
+          z[512] = make_float2(zh.x * gh, zh.y * gh);
+        }
+      } else {
+        do_pair(k1, wk1, avg[0], avg[1], bnd[0], bnd[1]);
+      }
+    }
+    if (!any_synth) continue;                  // uniform across the workgroup; the next group's first barrier orders the buffers
+    __syncthreads();
+    // ---- P3: z[m] = 1024 (y[2m], y[2m+1]); synthesis window (fft.js:63-65)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int m = t + 256 * r, i = 2 * m;
-      const float2 zz = zb[padz(m)];
-      const float pr0 = f32r((double)(zz.x * (1.0f / kM)) * (double)win[i]);
-      const float pr1 = f32r((double)(zz.y * (1.0f / kM)) * (double)win[i + 1]);
-      const int64_t s = pos + i;
-      const int o = (int)(s & (kN - 1));
-      if (s < n) ola[o] = f32r((double)ola[o] + (double)pr0);
-      if (s + 1 < n) ola[o + 1] = f32r((double)ola[o + 1] + (double)pr1);
+    for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
+    fft1024_wave<true>(v, zw, T);              // contains the barrier between every wavefront's reads above and the writes below
+    if (synth) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int m = ob + 16 * j;
+        const float2 wv = ((const float2*)win)[m];
+        zw[m] = make_float2((v[j].x * (1.0f / kM)) * wv.x, (v[j].y * (1.0f / kM)) * wv.y);
+      }
     }
     __syncthreads();
-    // samples [pos, pos + 512) are complete: normalise by 4, mix, emit, and free the ring slots
-    for (int i = t; i < kHop; i += 256) {
-      const int64_t s = pos + i;
-      const int o = (int)(s & (kN - 1));
-      if (f >= f0) {
-        const float w = f32r((double)ola[o] / 4.0);
-        y[s] = f32r((double)xin[o] * dry + (double)w * wetm);
+    // ---- P4: overlap-add (dynamic-processor.js:483-487) in frame order; thread-private ring slots, so no barrier in between
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = ola[t + 256 * j];
+    for (int w = 0; w < 4; w++) {
+      const int64_t fw = g + w;
+      if (fw >= f1) break;
+      if (fw + 3 < f0) continue;
+      const float* yw = (const float*)buf[w];
+      const int64_t pos = fw * kHop;
+      const int rot = (int)(pos & (kN - 1));
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int o = t + 256 * j;
+        const int i = (o - rot) & (kN - 1);
+        const int64_t s = pos + i;
+        if (s < n) acc[j] = acc[j] + yw[i];
+        if (i < kHop) {                        // samples [pos, pos + 512) are complete: normalise by 4, mix, emit, free the slot
+          if (fw >= f0) {
+            const float wv = acc[j] * 0.25f;
+            y[s] = f32r((double)load_in(s) * dry + (double)wv * wetm);
+          }
+          acc[j] = 0.0f;
+        }
       }
-      ola[o] = 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++) ola[t + 256 * j] = acc[j];
   }
   __syncthreads();
   if (!last_seg) return;
@@ -353,10 +489,9 @@ __global__ __launch_bounds__(256) void k_dh_apply(const float* __restrict__ in, 
   const int64_t done = F > 0 ? F * kHop : 0;
   const int64_t ring_end = F > 0 ? (F - 1) * kHop + kN : 0;           // samples below this are in the ring
   for (int64_t s = done + t; s < n; s += 256) {
-    float xv, w = 0.0f;
-    if (s < ring_end) { const int o = (int)(s & (kN - 1)); xv = xin[o]; w = f32r((double)ola[o] / 4.0); }
-    else xv = load_in(s);
-    y[s] = f32r((double)xv * dry + (double)w * wetm);
+    float w = 0.0f;
+    if (s < ring_end) w = f32r((double)ola[(int)(s & (kN - 1))] / 4.0);
+    y[s] = f32r((double)load_in(s) * dry + (double)w * wetm);
   }
 }
 
@@ -389,20 +524,21 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   DevBuf plan, twb, winb, rms, gdb;
   int rc;
   rc = plan.alloc(sizeof(dp)); if (rc) return rc;
-  rc = twb.alloc(sizeof(float2) * (kTwA + kTwB)); if (rc) return rc;
+  rc = twb.alloc(sizeof(float2) * (kTw1 + kTwB)); if (rc) return rc;
   rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   rc = gdb.alloc(sizeof(double) * nf * kBands * nchan); if (rc) return rc;
-  std::vector<float2> tw(kTwA + kTwB);
+  std::vector<float2> tw(kTw1 + kTwB);
   std::vector<float> win(kN);
-  for (int k = 0; k < kTwA; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
-  for (int k = 0; k < kTwB; k++) { const double a = -2 * M_PI * k / kN; tw[kTwA + k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  for (int k = 0; k < kTw1; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+  for (int k = 0; k < kTwB; k++) { const double a = -2 * M_PI * k / kN; tw[kTw1 + k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int i = 0; i < kN; i++) win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / (kN - 1))));     // utils.js:98-104
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
   if (dp.nframes > 0) {
-    int64_t gx = dp.nframes < 2048 ? dp.nframes : 2048;
+    const int64_t ngroups = (dp.nframes + 3) / 4;
+    int64_t gx = ngroups < 2048 ? ngroups : 2048;
     WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
           se = follower_step(se, (double)a[k], sA, sR);
           const double diff = fe - se;
           // strength = min(|diff| / max-guard(slowEnv, 1e-4), 1); gain towards the transient or the sustain target
-          const double st = fmin(fabs(diff) / (se > 0.0001 ? se : 0.0001), 1.0);
+          const double st = fmin(div_fast(fabs(diff), se > 0.0001 ? se : 0.0001), 1.0);   // den in [1e-4, ~10]
           const double target = 1 + (diff > 0 ? tg : sg) * st;
           u[k] = osm * target;
         }

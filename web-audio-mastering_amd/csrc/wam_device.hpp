@@ -50,6 +50,17 @@ __device__ __forceinline__ const T* reload_each_tile(const T* p) {
   return p;
 }
 
+// num / den for operands in a "safe" range (no overflow / underflow / zero of den, |quotient| moderate): v_rcp_f64, two
+// Newton steps, one residual correction of the quotient.  Error <= 1 ulp (the IEEE sequence with div_scale / div_fmas /
+// div_fixup is ~3x the instructions); used only where the result is rounded to f32 further down.
+__device__ __forceinline__ double div_fast(double num, double den) {
+  double y = __builtin_amdgcn_rcp(den);
+  y = fma(fma(-den, y, 1.0), y, y);
+  y = fma(fma(-den, y, 1.0), y, y);
+  const double q = num * y;
+  return fma(fma(-den, q, num), y, q);
+}
+
 // tanh in double, |error| < 2e-15 absolute (the callers add the result to a signal that is then
 // rounded to f32).  tanh|x| = (1 - t) / (1 + t), t = exp(-2|x|): range reduction by ln 2,
 // degree-12 Taylor polynomial on |r| <= ln2/2, reciprocal by v_rcp_f64 + two Newton steps.
