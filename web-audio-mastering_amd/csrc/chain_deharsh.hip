@@ -167,11 +167,10 @@ __device__ __forceinline__ BinPair split_pair(float2 zk, float2 zm, float2 w) {
   return p;
 }
 
-// windowed analysis frame of this lane: v[r] = (x[pos + 2 m] w[2 m], x[pos + 2 m + 1] w[2 m + 1]), m = 64 r + lane (fft.js:43-45)
-__device__ __forceinline__ void load_frame(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, float2 v[16]) {
-  const int lane = lane_id();
-  const float* xp = x + pos + 2 * lane;
-  const float2* wp = (const float2*)win + lane;                    // the window table is 8-byte aligned, 2 m is even
+// analysis frame of this lane: raw[r] = (x[pos + 2 m], x[pos + 2 m + 1]), m = 64 r + lane - loads only, so that a caller can issue
+// them a frame ahead
+__device__ __forceinline__ void load_frame_raw(const float* __restrict__ x, int64_t pos, float2 v[16]) {
+  const float* xp = x + pos + 2 * lane_id();
   if (((uintptr_t)xp & 7) == 0) {                                  // uniform: pos is even, so this is the alignment of x
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = *(const float2*)(xp + 128 * r);
@@ -179,15 +178,23 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ x, int64_t 
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = make_float2(xp[128 * r], xp[128 * r + 1]);
   }
+}
+// input gain, (input[i] || 0), analysis window (fft.js:43-45)
+__device__ __forceinline__ void window_frame(float2 v[16], const float* __restrict__ win, double pre_gain) {
+  const float2* wp = (const float2*)win + lane_id();               // the window table is 8-byte aligned, 2 m is even
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     float v0 = v[r].x, v1 = v[r].y;
     if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
-    if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
+    if (!(v0 == v0)) v0 = 0.0f;
     if (!(v1 == v1)) v1 = 0.0f;
     const float2 w = wp[64 * r];
     v[r] = make_float2(v0 * w.x, v1 * w.y);                        // one f32 rounding of the exact product, as f32(double product)
   }
+}
+__device__ __forceinline__ void load_frame(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, float2 v[16]) {
+  load_frame_raw(x, pos, v);
+  window_frame(v, win, pre_gain);
 }
 
 // Band RMS of every frame.  grid = (frame groups, channels); wavefront w of a workgroup takes frame 4 g + w of its groups
@@ -286,20 +293,19 @@ __device__ __forceinline__ float band_gain_db_of(double env, const DeharshPlan& 
   return f32r(gdb);
 }
 
-// Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43).  band_env: [chan][frame][7]
-// double.  The release coefficient is per SAMPLE but the follower is stepped per frame, so its memory spans the whole
+// Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43) and the soft-knee gain of its
+// envelope.  band_gdb: [chan][frame][7] float (the reference keeps the gains in a Float32Array).  The release coefficient is per SAMPLE but the follower is stepped per frame, so its memory spans the whole
 // track (no warm-up segmentation); instead one workgroup per (channel, band) walks the frames in tiles of 4,096 with
-// the same policy-iteration scan as the per-sample followers (an hour at 96 kHz is 337 k frames = 83 tiles).  Only
-// the recurrence runs here - the logarithm and the knee are evaluated by the consumer.
+// the same policy-iteration scan as the per-sample followers (an hour at 96 kHz is 337 k frames = 83 tiles).
 __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
-                                                        double* __restrict__ band_env) {
+                                                        float* __restrict__ band_gdb) {
   __shared__ double lds_scan[kSlotDoubles];
   const DeharshPlan& P = *dp;
   const int chan = blockIdx.x / kBands, b = blockIdx.x % kBands;
   const double A = P.A[b], R = P.R[b];
   const int64_t F = P.nframes;
   const float* src = band_rms + (int64_t)chan * F * kBands + b;
-  double* dst = band_env + (int64_t)chan * F * kBands + b;
+  float* dst = band_gdb + (int64_t)chan * F * kBands + b;
   LdsSlots slots(lds_scan);
   double Senv = 0;
   const int64_t ntiles = (F + kTile - 1) / kTile;
@@ -313,185 +319,170 @@ __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < C; k++) {
       e = follower_step(e, (double)a[k], A, R);
-      if (base + k < F) dst[(base + k) * kBands] = e;
+      if (base + k < F) dst[(base + k) * kBands] = band_gain_db_of(e, P, b);
     }
   }
 }
 
-// Synthesis.  grid = (segments, channels): a workgroup owns the frames [f0, f1) of its segment and emits the samples
-// [f0 * 512, f1 * 512) (the last segment also the tail).  Frame-to-frame state is the per-bin resonance EMA
-// (avg' = 0.3 mag + 0.7 avg) and the overlap-add ring; a segment rebuilds both by re-running `warm` frames before
-// f0: the EMA forgets its start value as 0.7^warm, and the ring needs the three frames before f0.  Warm-up frames
-// more than three before f0 skip the inverse transform.
-//
-// Frames are taken four at a time, one per wavefront, in four phases separated by workgroup barriers:
-//   P1 (per wavefront)  windowed frame -> FFT -> Z in the wavefront's LDS buffer
-//   P2 (per bin)        thread t owns the bin pairs (t, 1024 - t) and (t + 256, 768 - t) with their EMA state in registers
-//                       and walks the four frames IN ORDER: split, resonance, gain, fold back into the same slots
-//   P3 (per wavefront)  inverse FFT, 1/1024, synthesis window -> the frame's 2048 output samples in the buffer
-//   P4 (per ring slot)  thread t owns the overlap-add slots t + 256 j: adds the four frames in order, emits the
-//                       512 samples each frame completes (normalise, 85/15 mix) and clears their slots
+// Synthesis.  Every WAVEFRONT owns one segment [f0, f1) of one channel's frames and emits the samples [f0 * 512, f1 * 512)
+// (the last segment also the tail); the four wavefronts of a workgroup take four neighbouring segments and share nothing
+// but the twiddle tables, so after set-up there is no workgroup barrier at all: a wavefront that waits (global load, LDS
+// round trip) leaves its SIMD to the wavefronts of other workgroups instead of stalling three siblings at a barrier.
+// Frame-to-frame state, all in registers: the per-bin resonance EMA (avg' = 0.3 mag + 0.7 avg) of the lane's bin pairs
+// (k, 1024 - k), k = lane + 64 j, and the overlap-add ring slots lane + 64 j, j = 0..31.  A segment rebuilds both by
+// re-running `warm` frames before f0: the EMA forgets its start value as 0.7^warm, and the ring needs the three frames
+// before f0.  Warm-up frames more than three before f0 skip the inverse transform.  Per frame:
+//   windowed frame -> FFT -> Z in LDS -> split, resonance, gain, fold back (own slots) -> inverse FFT, 1/1024,
+//   synthesis window -> the frame's 2048 samples in LDS -> overlap-add into the ring registers, emit the 512 samples the
+//   frame completes (normalise, 85/15 mix), clear their slots.
 __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                      const DeharshPlan* __restrict__ dp, const float2* __restrict__ twg,
-                                                     const float* __restrict__ wing, const double* __restrict__ band_env, double pre_gain,
-                                                     int64_t seg_frames, int64_t warm) {
+                                                     const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
+                                                     int64_t seg_frames, int64_t nseg, int64_t warm) {
   __shared__ float2 buf[4][kWaveBuf];
-  __shared__ float ola[kN];      // overlap-add ring: sample s at ola[s & 2047]
   __shared__ float2 tws[kTwl + kTwq];
-  __shared__ float bg[2][4][8];  // band gains of the group's four frames, double-buffered by group parity
+  __shared__ float2 twBs[kM / 2];              // W2048^k, k < 512
+  __shared__ float bgs[4][8];
   const DeharshPlan& P = *dp;
-  const float2* twB = twg + kTw1;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
-  const int t = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423
+  const int lane = lane_id(), wave = wave_id();
+  const float dry = 1 - 0.15, wetm = 0.15;                          // preset dryWetMix 0.15, dynamic-processor.js:419-423
   const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
-  for (int i = t; i < kN; i += 256) ola[i] = 0.0f;
+  WaveTw T; load_wave_tw(twg, T, tws);
+  for (int i = threadIdx.x; i < kM / 2; i += 256) twBs[i] = twg[kTw1 + i];
+  __syncthreads();
+  const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
+  if (seg >= nseg) return;                       // no workgroup barrier below
   auto load_in = [&](int64_t s) -> float {
     float v = (s < n) ? x[s] : 0.0f;
     if (pre_gain != 1.0) v = f32r((double)v * pre_gain);
     return v;
   };
   const int64_t F = P.nframes;
-  const int64_t f0 = (int64_t)blockIdx.x * seg_frames;
+  const int64_t f0 = seg * seg_frames;
   int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
   const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
   const bool last_seg = f1 >= F;
-  WaveTw T; load_wave_tw(twg, T, tws);
-  __syncthreads();
   const int ob = wave_out_base();
   float2* zw = buf[wave];
-  // bins of this thread in P2: the pairs (k1, 1024 - k1) and (k2, 1024 - k2), k1 = t, k2 = t + 256; thread 0 holds DC and, in
-  // the slot of "1024 - 0", bin 512.  avg[] = the resonance detector's running mean of those four bins.
-  const int k1 = t, k2 = t + 256;
-  const int bnd[4] = { P.band_of[k1], P.band_of[t == 0 ? 512 : kM - k1], P.band_of[k2], P.band_of[kM - k2] };
-  const float2 wk1 = twB[k1], wk2 = twB[k2];
-  float avg[4] = {0, 0, 0, 0};
-  int par = 0;
-  for (int64_t g = fs; g < f1; g += 4, par ^= 1) {
-    const int64_t f = g + wave;                // this wavefront's frame
-    const bool valid = f < f1;
-    const bool synth = valid && f + 3 >= f0;   // this frame's output reaches samples the segment emits
-    const bool any_synth = g + 3 + 3 >= f0;    // some frame of the group is synthesised (uniform)
-    float2 v[16];
-    // ---- P1
-    if (valid) load_frame(x, f * kHop, win, pre_gain, v);
-    else {
+  float* bg = bgs[wave];
+  uint64_t bands = 0;                           // 3 bits per bin: bins k = lane + 64 j at 3 j, bins 1024 - k at 24 + 3 j
 #pragma unroll
-      for (int r = 0; r < 16; r++) v[r] = make_float2(0.f, 0.f);
-    }
-    if (t < 28) { const int w = t / kBands, b = t - w * kBands; if (g + w < f1) bg[par][w][b] = band_gain_db_of(band_env[(chan * F + g + w) * kBands + b], P, b); }
-    __syncthreads();                           // the previous group's P4 reads of the buffers are done
+  for (int j = 0; j < 8; j++) {
+    const int k = lane + 64 * j;
+    bands |= (uint64_t)P.band_of[k] << (3 * j) | (uint64_t)P.band_of[k == 0 ? 512 : kM - k] << (24 + 3 * j);
+  }
+  float avg[16], acc[32];
+#pragma unroll
+  for (int j = 0; j < 16; j++) avg[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 32; j++) acc[j] = 0.0f;
+  for (int64_t f = fs; f < f1; f++) {
+    const bool synth = f + 3 >= f0;            // this frame's output reaches samples the segment emits
+    const bool first = f == fs;                // the detector's first frame (:203-207); a warm start for later segments
+    float2 v[16];
+    load_frame(x, f * kHop, win, pre_gain, v);
+    if (lane < kBands) bg[lane] = band_gdb[(chan * F + f) * kBands + lane];
+    wave_sync();                               // the previous frame's reads of zw precede the exchange's writes
     fft1024_wave<false>(v, zw, T);
 #pragma unroll
     for (int j = 0; j < 16; j++) zw[ob + 16 * j] = v[j];
-    __syncthreads();
-    // ---- P2
-    for (int w = 0; w < 4; w++) {
-      const int64_t fw = g + w;
-      if (fw >= f1) break;                     // uniform
-      float2* z = buf[w];
-      const bool syn = fw + 3 >= f0;
-      const bool first = fw == fs;             // the detector's first frame (:203-207); a warm start for later segments
-      // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
-      // (single precision throughout: the spectrum itself is a float32 FFT, the detector's thresholds are continuous)
-      auto bin_gain = [&](float mag, float& av_state, int band) -> float {
-        float gdb = bg[par][w][band];
-        if (first) av_state = mag;
-        else {
-          av_state = fmaf(0.3f, mag, 0.7f * av_state);
-          const float av = av_state;
-          if (av > 1e-10f && mag > av * 1.5f) {
-            const float res = fminf(1.0f, (mag * __builtin_amdgcn_rcpf(av) - 1.5f) * 0.5f);
-            gdb = fmaf(-0.6f, res, gdb);                           // -3 dB * res * 0.2 (:372-376)
-          }
+    wave_sync();
+    // resonance detector (:194-233) and bin gain (:354-382) of one bin; returns the linear gain
+    // (single precision throughout: the spectrum itself is a float32 FFT, the detector's thresholds are continuous)
+    auto bin_gain = [&](float mag, float& av_state, int band) -> float {
+      float gdb = bg[band];
+      if (first) av_state = mag;
+      else {
+        av_state = fmaf(0.3f, mag, 0.7f * av_state);
+        const float av = av_state;
+        if (av > 1e-10f && mag > av * 1.5f) {
+          const float res = fminf(1.0f, (mag * __builtin_amdgcn_rcpf(av) - 1.5f) * 0.5f);
+          gdb = fmaf(-0.6f, res, gdb);                             // -3 dB * res * 0.2 (:372-376)
         }
-        return exp2f(gdb * 0.16609640474436813f);                  // 10^(gdb/20)
-      };
-      // scale the bins (mirror implied, :471-476) and fold the spectrum back into the 1024-point input of the inverse:
-      //   Ye = (Y[k] + conj Y[M-k]) / 2, Yo = (Y[k] - conj Y[M-k]) / 2 conj(W^k), Z'[k] = Ye + i Yo, Z'[M-k] = conj Ye + i conj Yo
-      auto do_pair = [&](int k, float2 wtw, float& av_k, float& av_m, int band_k, int band_m) {
-        const float2 zk = z[k], zm = z[kM - k];
-        const BinPair p = split_pair(zk, zm, wtw);
-        const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xmc = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
-        const float gk = bin_gain(sqrtf(xk.x * xk.x + xk.y * xk.y), av_k, band_k);
-        const float gm = bin_gain(sqrtf(xmc.x * xmc.x + xmc.y * xmc.y), av_m, band_m);
-        if (!syn) return;
-        const float2 yk = make_float2(xk.x * gk, xk.y * gk), ymc = make_float2(xmc.x * gm, xmc.y * gm);
-        const float2 ye = make_float2(0.5f * (yk.x + ymc.x), 0.5f * (yk.y + ymc.y));
-        const float2 yo = cmulc(make_float2(0.5f * (yk.x - ymc.x), 0.5f * (yk.y - ymc.y)), wtw);
-        z[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
-        z[kM - k] = make_float2(ye.x + yo.y, yo.x - ye.y);
-      };
-      do_pair(k2, wk2, avg[2], avg[3], bnd[2], bnd[3]);
-      if (t == 0) {
-        const float2 z0 = z[0], zh = z[512];
-        const float x0 = z0.x + z0.y, xny = z0.x - z0.y;        // X[0] and X[1024] are real; the Nyquist bin is not scaled
-        const float g0 = bin_gain(fabsf(x0), avg[0], bnd[0]);
-        const float gh = bin_gain(sqrtf(zh.x * zh.x + zh.y * zh.y), avg[1], bnd[1]);
-        if (syn) {
+      }
+      return exp2f(gdb * 0.16609640474436813f);                    // 10^(gdb/20)
+    };
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if ((j & 1) == 0) __builtin_amdgcn_sched_barrier(0);      // two pairs in flight, not eight: register pressure
+      const int k = lane + 64 * j;
+      const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;
+      if (j == 0 && k == 0) {
+        const float2 z0 = zw[0], zh = zw[512];
+        const float x0 = z0.x + z0.y, xny = z0.x - z0.y;          // X[0] and X[1024] are real; the Nyquist bin is not scaled
+        const float g0 = bin_gain(fabsf(x0), avg[0], bk);
+        const float gh = bin_gain(sqrtf(zh.x * zh.x + zh.y * zh.y), avg[1], bm);
+        if (synth) {
           const float y0 = x0 * g0;
-          z[0] = make_float2(0.5f * (y0 + xny), 0.5f * (y0 - xny));
-          z[512] = make_float2(zh.x * gh, zh.y * gh);
+          zw[0] = make_float2(0.5f * (y0 + xny), 0.5f * (y0 - xny));
+          zw[512] = make_float2(zh.x * gh, zh.y * gh);
         }
       } else {
-        do_pair(k1, wk1, avg[0], avg[1], bnd[0], bnd[1]);
-      }
-    }
-    if (!any_synth) continue;                  // uniform across the workgroup; the next group's first barrier orders the buffers
-    __syncthreads();
-    // ---- P3: z[m] = 1024 (y[2m], y[2m+1]); synthesis window (fft.js:63-65)
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
-    fft1024_wave<true>(v, zw, T);              // contains the barrier between every wavefront's reads above and the writes below
-    if (synth) {
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const int m = ob + 16 * j;
-        const float2 wv = ((const float2*)win)[m];
-        zw[m] = make_float2((v[j].x * (1.0f / kM)) * wv.x, (v[j].y * (1.0f / kM)) * wv.y);
-      }
-    }
-    __syncthreads();
-    // ---- P4: overlap-add (dynamic-processor.js:483-487) in frame order; thread-private ring slots, so no barrier in between
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = ola[t + 256 * j];
-    for (int w = 0; w < 4; w++) {
-      const int64_t fw = g + w;
-      if (fw >= f1) break;
-      if (fw + 3 < f0) continue;
-      const float* yw = (const float*)buf[w];
-      const int64_t pos = fw * kHop;
-      const int rot = (int)(pos & (kN - 1));
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int o = t + 256 * j;
-        const int i = (o - rot) & (kN - 1);
-        const int64_t s = pos + i;
-        if (s < n) acc[j] = acc[j] + yw[i];
-        if (i < kHop) {                        // samples [pos, pos + 512) are complete: normalise by 4, mix, emit, free the slot
-          if (fw >= f0) {
-            const float wv = acc[j] * 0.25f;
-            y[s] = f32r((double)load_in(s) * dry + (double)wv * wetm);
-          }
-          acc[j] = 0.0f;
+        // scale the bins (mirror implied, :471-476) and fold the spectrum back into the 1024-point input of the inverse:
+        //   Ye = (Y[k] + conj Y[M-k]) / 2, Yo = (Y[k] - conj Y[M-k]) / 2 conj(W^k), Z'[k] = Ye + i Yo, Z'[M-k] = conj Ye + i conj Yo
+        const float2 zk = zw[k], zm = zw[kM - k];
+        const float2 wtw = twBs[k];
+        const BinPair p = split_pair(zk, zm, wtw);
+        const float2 xk = make_float2(p.xe.x + p.t.x, p.xe.y + p.t.y), xmc = make_float2(p.xe.x - p.t.x, p.xe.y - p.t.y);
+        const float gk = bin_gain(sqrtf(xk.x * xk.x + xk.y * xk.y), avg[2 * j], bk);
+        const float gm = bin_gain(sqrtf(xmc.x * xmc.x + xmc.y * xmc.y), avg[2 * j + 1], bm);
+        if (synth) {
+          const float2 yk = make_float2(xk.x * gk, xk.y * gk), ymc = make_float2(xmc.x * gm, xmc.y * gm);
+          const float2 ye = make_float2(0.5f * (yk.x + ymc.x), 0.5f * (yk.y + ymc.y));
+          const float2 yo = cmulc(make_float2(0.5f * (yk.x - ymc.x), 0.5f * (yk.y - ymc.y)), wtw);
+          zw[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
+          zw[kM - k] = make_float2(ye.x + yo.y, yo.x - ye.y);
         }
       }
     }
+    if (!synth) continue;                      // uniform across the wavefront
+    wave_sync();
+    // inverse: z[m] = 1024 (y[2m], y[2m+1]); synthesis window (fft.js:63-65)
 #pragma unroll
-    for (int j = 0; j < 8; j++) ola[t + 256 * j] = acc[j];
+    for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
+    fft1024_wave<true>(v, zw, T);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int m = ob + 16 * j;
+      const float2 wv = ((const float2*)win)[m];
+      zw[m] = make_float2((v[j].x * (1.0f / kM)) * wv.x, (v[j].y * (1.0f / kM)) * wv.y);
+    }
+    wave_sync();
+    // overlap-add (dynamic-processor.js:483-487): ring slot o = lane + 64 j holds sample s with s & 2047 = o; this frame
+    // covers s = pos + i, i = (o - pos) & 2047, and completes the 512 samples whose slots are j >> 3 = f & 3
+    const float* yw = (const float*)zw;
+    const int64_t pos = f * kHop;
+    const int rot = (int)(pos & (kN - 1)), jdone = (int)(f & 3);
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+      const int i = (lane + 64 * j - rot) & (kN - 1);
+      acc[j] += yw[i];
+      if ((j >> 3) == jdone) {                 // uniform
+        if (f >= f0) {
+          const int64_t s = pos + i;
+          y[s] = f32r((double)load_in(s) * (double)dry + (double)(acc[j] * 0.25f) * (double)wetm);
+        }
+        acc[j] = 0.0f;
+      }
+    }
   }
-  __syncthreads();
   if (!last_seg) return;
   // tail: samples after the last frame's first hop keep their partial overlap-add sums (or none)
+  wave_sync();
+  float* ring = (float*)zw;
+#pragma unroll
+  for (int j = 0; j < 32; j++) ring[lane + 64 * j] = acc[j];
+  wave_sync();
   const int64_t done = F > 0 ? F * kHop : 0;
   const int64_t ring_end = F > 0 ? (F - 1) * kHop + kN : 0;           // samples below this are in the ring
-  for (int64_t s = done + t; s < n; s += 256) {
+  for (int64_t s = done + lane; s < n; s += 64) {
     float w = 0.0f;
-    if (s < ring_end) w = f32r((double)ola[(int)(s & (kN - 1))] / 4.0);
-    y[s] = f32r((double)load_in(s) * dry + (double)w * wetm);
+    if (s < ring_end) w = ring[(int)(s & (kN - 1))] * 0.25f;
+    y[s] = f32r((double)load_in(s) * (double)dry + (double)w * (double)wetm);
   }
 }
 
@@ -527,7 +518,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   rc = twb.alloc(sizeof(float2) * (kTw1 + kTwB)); if (rc) return rc;
   rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
-  rc = gdb.alloc(sizeof(double) * nf * kBands * nchan); if (rc) return rc;
+  rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   std::vector<float2> tw(kTw1 + kTwB);
   std::vector<float> win(kN);
   for (int k = 0; k < kTw1; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
@@ -542,13 +533,14 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
-               plan.as<DeharshPlan>(), nchan, gdb.as<double>());
+               plan.as<DeharshPlan>(), nchan, gdb.as<float>());
   }
+  // segments are walked by wavefronts, four to a workgroup: aim at ~16 k wavefronts (12 are resident per CU)
   const int64_t warm = tuning().dh_warm_frames;
-  const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, 8192);
+  const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
-  WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)nseg, (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
-             winb.as<float>(), (const double*)gdb.as<double>(), pre_gain, seg, warm);
+  WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
+             winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return
   return WAM_OK;
 }

@@ -93,11 +93,11 @@ inline int64_t meter_warm(int64_t hop, double sr) {
 // for about `want_wgs` workgroups, but never so short that the warm-up re-run costs more than a quarter of the work.
 // With few walkers (one track) the chip is idle anyway, so latency wins: segments shrink until the launch has one
 // workgroup per resident slot (2 per CU), whatever the warm-up overhead.
-inline int64_t pick_segment_tiles(int64_t walkers, int64_t ntiles, int64_t warm, int64_t override_tiles, int64_t want_wgs = 2048) {
+inline int64_t pick_segment_tiles(int64_t walkers, int64_t ntiles, int64_t warm, int64_t override_tiles, int64_t want_wgs = 2048,
+                                  int64_t slots = 512) {
   if (override_tiles > 0) return override_tiles;
   if (ntiles < 1) return 1;
   if (walkers < 1) walkers = 1;
-  const int64_t slots = 512;
   const int64_t seg_many = (ntiles * walkers + want_wgs - 1) / want_wgs;
   int64_t seg_fill = (ntiles * walkers + slots - 1) / slots;
   if (seg_fill < 8) seg_fill = 8;
