@@ -91,42 +91,49 @@ def pmc_traffic(kernel, tracks_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_summary.csv: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH_SIZE doubled per the gfx950 correction)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rows = list(csv.DictReader(f))
-    meta = [r for r in rows if r["kernel"] == "#tracks_per_launch"]
-    ref_tracks = float(meta[0]["launches"]) if meta else None
-    for r in rows:
-        if r["kernel"] == kernel:
-            try:
-                b = (float(r["fetch_GB_per_launch_x2"]) + float(r["write_GB_per_launch"])) * 1e9
-            except ValueError:
-                return None
-            if ref_tracks and ref_tracks != tracks_per_launch:
-                b *= tracks_per_launch / ref_tracks          # traffic is proportional to the tracks a launch covers
-            return b
+    for name in ("r01_pmc_summary.csv", "r01_pmc_meter_summary.csv"):      # chain passes, meter-workload passes
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rows = list(csv.DictReader(f))
+        meta = [r for r in rows if r["kernel"] == "#tracks_per_launch"]
+        ref_tracks = float(meta[0]["launches"]) if meta else None
+        for r in rows:
+            if r["kernel"] == kernel:
+                try:
+                    b = (float(r["fetch_GB_per_launch_x2"]) + float(r["write_GB_per_launch"])) * 1e9
+                except ValueError:
+                    return None
+                if ref_tracks and ref_tracks != tracks_per_launch:
+                    b *= tracks_per_launch / ref_tracks          # traffic is proportional to the tracks a launch covers
+                return b
     return None
 
 
 def cpu_baseline(workload, sr=SR):
-    """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload."""
+    """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload: whole tracks of the
+    workload's shape (3-min stereo; a 60 s excerpt for the long-form case), one after the other on one core, until about
+    10 s of CPU time have been spent."""
     import oracle_lib as O
     chain = workload in ("chain", "single", "longform")
-    secs = 20 if chain else (30 if workload == "stft" else 60)
-    x = O.synth(0, NCH, secs * sr, sr, SYNTH)
-    t0 = time.perf_counter()
-    if chain:
-        O.render_chain(x, sr, C2_SETTINGS, "export")
-    elif workload == "stft":
-        O.stft_db(x, sr, 4096, 1024)
-    else:
-        O.measure_lufs(x, sr)
-        O.true_peak_db(x)
-    dt = time.perf_counter() - t0
-    return {"value": secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port",
-            "sample": f"1 track x {secs} s stereo {sr // 1000} kHz, same synthetic generator and settings, oracle/wam_oracle.c (C restatement of the reference JS), {dt:.1f} s wall"}
+    secs = 60 if workload == "longform" else 180
+    budget, done, dt = 10.0, 0, 0.0
+    while dt < budget and done < 64:
+        x = O.synth(done, NCH, secs * sr, sr, SYNTH)
+        t0 = time.perf_counter()
+        if chain:
+            O.render_chain(x, sr, C2_SETTINGS, "export")
+        elif workload == "stft":
+            O.stft_db(x, sr, 4096, 1024)
+        else:
+            O.measure_lufs(x, sr)
+            O.true_peak_db(x)
+        dt += time.perf_counter() - t0
+        done += 1
+    return {"value": done * secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port",
+            "sample": f"{done} track(s) x {secs} s stereo {sr // 1000} kHz, same synthetic generator and settings, oracle/wam_oracle.c "
+                      f"(C restatement of the reference JS, one thread), {dt:.1f} s of CPU time"}
 
 
 def main():
@@ -224,8 +231,10 @@ def main():
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch), "avg_launch_ms": avg_ms,
                             "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
-                            "note": "the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,400 VALU "
-                                    "lane-instructions per 16 algorithmic bytes against a machine balance of ~5 per byte"}
+                            "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,300 VALU "
+                                     "lane-instructions per 16 algorithmic bytes against a machine balance of ~5 per byte") if chain_like else
+                                    ("two f64 K-weighting biquad scans + the 4-point peak interpolation per 4-byte sample: VALU-bound "
+                                     "(DESIGN.md 5)" if wl == "meter" else "f32 butterflies in LDS; see DESIGN.md 5")}
             else:
                 roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                             "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}

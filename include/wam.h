@@ -167,6 +167,13 @@ int wam_limiter(const float* const* ch, int nch, int64_t n, double sample_rate,
                 double ceiling_linear, double lookahead_ms, double release_ms, double knee_db,
                 int preserve_transients, float* const* out);
 
+/* applyLookaheadLimiter(audioBuffer, ...), web/lib/dsp/limiter.js:155-362: the library twin, which the sync API and
+ * normalizeToLUFS (normalizer.js:83) call.  Same stages; its oversampled soft-knee pass starts the running maximum at 0
+ * instead of |y2| (limiter.js:107 vs dsp-worker.js:260). */
+int wam_limiter_lib(const float* const* ch, int nch, int64_t n, double sample_rate,
+                    double ceiling_linear, double lookahead_ms, double release_ms, double knee_db,
+                    int preserve_transients, float* const* out);
+
 /* Single stages, same arithmetic as inside wam_render_chain (lib/dsp/index.js names). */
 int wam_final_filters(const float* const* ch, int nch, int64_t n, double sample_rate,
                       int highpass, int lowpass, float* const* out);          /* final-filters.js:96 */

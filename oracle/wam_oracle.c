@@ -437,9 +437,41 @@ void ora_soft_knee_oversampled(const float* in, int64_t n, double ceiling, doubl
   }
 }
 
+/* ref: web/lib/dsp/limiter.js:81-128 applySoftKneeOversampled (lib twin: the running maximum starts at 0, :107, and the
+ * interpolation is interpolateCatmullRom, utils.js:143-153) */
+void ora_soft_knee_oversampled_lib(const float* in, int64_t n, double ceiling, double knee_db, float* out) {
+  double p[4] = {0, 0, 0, 0};
+  for (int64_t i = 0; i < n; i++) {
+    p[0] = p[1]; p[1] = p[2]; p[2] = p[3]; p[3] = in[i];
+    if (i < 3) { out[i] = F32(soft_knee_curve(in[i], ceiling, knee_db)); continue; }
+    const double a0 = -0.5 * p[0] + 1.5 * p[1] - 1.5 * p[2] + 0.5 * p[3];
+    const double a1 = p[0] - 2.5 * p[1] + 2 * p[2] - 0.5 * p[3];
+    const double a2 = -0.5 * p[0] + 0.5 * p[2];
+    double m = 0;
+    for (int j = 1; j <= 3; j++) {
+      const double t = j * 0.25, t2 = t * t, t3 = t2 * t;
+      const double v = fabs(a0 * t3 + a1 * t2 + a2 * t + p[1]);
+      if (v > m) m = v;
+    }
+    if (m > ceiling) { const double gr = ceiling / m; out[i] = F32(soft_knee_curve((double)in[i] * gr, ceiling, knee_db)); }
+    else out[i] = F32(soft_knee_curve(in[i], ceiling, knee_db));
+  }
+}
+
+static void limiter_impl(const float* const* in, int nch, int64_t n, double sr, double ceil_lin, double lookahead_ms,
+                         double release_ms, double knee_db, int preserve, float* const* out, int lib_twin);
 /* ref: web/workers/dsp-worker.js:286-452 applyLookaheadLimiterToChannels */
 void ora_limiter(const float* const* in, int nch, int64_t n, double sr, double ceil_lin, double lookahead_ms,
                  double release_ms, double knee_db, int preserve, float* const* out) {
+  limiter_impl(in, nch, n, sr, ceil_lin, lookahead_ms, release_ms, knee_db, preserve, out, 0);
+}
+/* ref: web/lib/dsp/limiter.js:155-362 applyLookaheadLimiter - the same stages; only its soft-knee pass differs (above) */
+void ora_limiter_lib(const float* const* in, int nch, int64_t n, double sr, double ceil_lin, double lookahead_ms,
+                     double release_ms, double knee_db, int preserve, float* const* out) {
+  limiter_impl(in, nch, n, sr, ceil_lin, lookahead_ms, release_ms, knee_db, preserve, out, 1);
+}
+static void limiter_impl(const float* const* in, int nch, int64_t n, double sr, double ceil_lin, double lookahead_ms,
+                         double release_ms, double knee_db, int preserve, float* const* out, int lib_twin) {
   const int64_t L = (int64_t)floor(sr * lookahead_ms / 1000);
   const double rc = exp(-1 / (release_ms * sr / 1000));
   float* tm = NULL;
@@ -512,7 +544,8 @@ void ora_limiter(const float* const* in, int nch, int64_t n, double sr, double c
   float* tmp = falloc(n);
   for (int c = 0; c < nch; c++) {
     for (int64_t i = 0; i < n; i++) tmp[i] = F32((double)in[c][i] * (double)g[i]);
-    ora_soft_knee_oversampled(tmp, n, ceil_lin, knee_db, out[c]);
+    if (lib_twin) ora_soft_knee_oversampled_lib(tmp, n, ceil_lin, knee_db, out[c]);
+    else ora_soft_knee_oversampled(tmp, n, ceil_lin, knee_db, out[c]);
   }
   free(tmp); free(g); free(tm);
 }

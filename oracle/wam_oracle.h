@@ -53,6 +53,8 @@ void ora_soft_clip(const float* const* in, int nch, int64_t n, double sr, double
                    double release_ms, double drive, float* const* out);
 void ora_limiter(const float* const* in, int nch, int64_t n, double sr, double ceiling_lin, double lookahead_ms,
                  double release_ms, double knee_db, int preserve_transients, float* const* out);
+void ora_limiter_lib(const float* const* in, int nch, int64_t n, double sr, double ceiling_lin, double lookahead_ms,
+                     double release_ms, double knee_db, int preserve, float* const* out);
 void ora_soft_knee_oversampled(const float* in, int64_t n, double ceiling, double knee_db, float* out);
 void ora_normalize(const float* const* in, int nch, int64_t n, double sr, double target, double ceiling_db,
                    float* const* out, wam_normalize_result* res);

@@ -16,4 +16,10 @@ lines = out.splitlines()
 ncol = lines[0].count(",")
 lines.insert(1, "#tracks_per_launch,128" + "," * (ncol - 1))
 open(os.path.join(here, f"{pre}_pmc_summary.csv"), "w").write("\n".join(lines) + "\n")
+msrc = os.path.join(src, "meter", "pmc")
+if os.path.isdir(msrc):       # the meter workload's passes (k_meter, k_gate)
+    out = subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), msrc, str(NSC)], capture_output=True, text=True, check=True).stdout
+    lines = out.splitlines()
+    lines.insert(1, "#tracks_per_launch,128" + "," * (lines[0].count(",") - 1))
+    open(os.path.join(here, f"{pre}_pmc_meter_summary.csv"), "w").write("\n".join(lines) + "\n")
 print("ingested", tag)

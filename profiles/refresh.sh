@@ -14,4 +14,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 cd $R
 bash profiles/collect_pmc.sh $TAG --tracks-per-gpu 128
+bash profiles/collect_pmc.sh $TAG/meter --workload meter --tracks-per-gpu 128
 echo done

@@ -77,6 +77,16 @@ async function gpu() {
     const p = S['peaks_full']; const pab = track({ idx: p.idx, nch: p.nch, n: p.n_synth, sr: p.sr, opts: p.opts });
     const pk = wam.extractPeaks(pab, p.num_peaks), want = f32(p.peaks);
     ok(Array.isArray(pk) && pk.length === want.length && pk.every((v, i) => v === want[i]), 'extractPeaks identical'); }
+  // the library twins: applyLookaheadLimiter (limiter.js:155) and normalizeToLUFS with / without its limiter branch (normalizer.js:38)
+  { const L = JSON.parse(fs.readFileSync(path.join(DATA, 'libtwin.json'), 'utf8')).cases;
+    for (const name of ['lib_limiter_hot', 'lib_limiter_mono']) {
+      const c = L[name]; const r = wam.applyLookaheadLimiter(track(c), c.ceiling_lin);
+      for (let ch = 0; ch < c.nch; ch++) ok(maxAbsDiff(r.getChannelData(ch), f32(c.out[ch])) <= 1e-5, `${name} ch${ch}`);
+    }
+    for (const name of ['lib_normalize_limited', 'lib_normalize_plain']) {
+      const c = L[name]; const r = wam.normalizeToLUFS(track(c), c.target, c.ceiling_db);
+      for (let ch = 0; ch < c.nch; ch++) { const d = maxAbsDiff(r.getChannelData(ch), f32(c.out[ch])); ok(d <= 1e-5, `${name} ch${ch} max abs diff ${d}`); }
+    } }
   // full chain through the promise API, progress strings in worker order
   for (const name of ['chain_defaults_1s', 'chain_mono_1s', 'chain_preview_1s']) {
     const c = golden[name]; const ab = track(c);

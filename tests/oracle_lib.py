@@ -231,6 +231,12 @@ def limiter(chans, sr, ceiling_lin, lookahead_ms=3.0, release_ms=100.0, knee_db=
                                  C.c_double(release_ms), C.c_double(knee_db), C.c_int(int(preserve))))
 
 
+def limiter_lib(chans, sr, ceiling_lin, lookahead_ms=3.0, release_ms=100.0, knee_db=3.0, preserve=True):
+    return _run_stage(lib().ora_limiter_lib, chans,
+                      lambda n: (C.c_int(len(chans)), C.c_int64(n), C.c_double(sr), C.c_double(ceiling_lin), C.c_double(lookahead_ms),
+                                 C.c_double(release_ms), C.c_double(knee_db), C.c_int(int(preserve))))
+
+
 def soft_knee_oversampled(x, ceiling, knee_db=3.0):
     a = np.ascontiguousarray(x, dtype=np.float32)
     o = np.empty_like(a)

@@ -140,3 +140,20 @@ def test_ragged(n):
         assert maxerr(wam.apply_mastering_soft_clip(x, sr), O.soft_clip(x, sr)) <= TOL
     if has("wam_limiter"):
         assert maxerr(wam.apply_lookahead_limiter(x, sr, 0.891), O.limiter(x, sr, 0.891)) <= TOL
+
+
+def test_limiter_lib_twin():
+    """web/lib/dsp/limiter.js applyLookaheadLimiter: against the reference run (tests/golden/gen_libtwin.mjs) and the oracle."""
+    import json, os
+    with open(os.path.join(G.DATA, "libtwin.json")) as f:
+        cases = json.load(f)["cases"]
+    for name in ("lib_limiter_hot", "lib_limiter_hot_np", "lib_limiter_mono"):
+        c = cases[name]
+        x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+        got = wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], preserve_transients=c.get("preserve", True), twin="lib")
+        assert maxerr(got, G.chans(c["out"])) <= TOL, name
+    c = cases["lib_limiter_hot"]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    a = wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], twin="lib")
+    b = wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], twin="worker")
+    assert maxerr(a, b) > 1e-4                 # the twins do differ where the soft-knee pass engages

@@ -236,3 +236,23 @@ def test_extract_peaks_vs_reference():
         assert np.array_equal(got, G.f32(c["peaks"])), name
         n += 1
     assert n == 5
+
+
+def _libtwin_cases():
+    import json, os
+    with open(os.path.join(G.DATA, "libtwin.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_lib_twin_limiter_vs_reference():
+    """web/lib/dsp/limiter.js applyLookaheadLimiter (the library twin) and normalizeToLUFS's limiter branch, the reference run by
+    tests/golden/gen_libtwin.mjs; the twins must differ on the hot case, else the golden pins nothing."""
+    C = _libtwin_cases()
+    for name in ("lib_limiter_hot", "lib_limiter_hot_np", "lib_limiter_mono"):
+        c = C[name]
+        x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+        same(O.limiter_lib(x, c["sr"], c["ceiling_lin"], preserve=c.get("preserve", True)), G.chans(c["out"]))
+    c = C["lib_limiter_hot"]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    a, b = O.limiter(x, c["sr"], c["ceiling_lin"]), O.limiter_lib(x, c["sr"], c["ceiling_lin"])
+    assert any(not np.array_equal(p, q) for p, q in zip(a, b))

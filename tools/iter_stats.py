@@ -14,6 +14,8 @@ def stats(tag):
     out = (C.c_uint64 * 8)()
     wam._check(wam.lib().wam_debug_counters(out, 1))
     names = ("follower", "follower pair", "release")
+    if out[6] or out[7]:
+        print("   pair histogram (<=2, 3, 4, >4 iterations):", out[6] >> 32, out[6] & 0xffffffff, out[7] >> 32, out[7] & 0xffffffff)
     print(tag, "; ".join(f"{names[s]}: {out[2*s+1] / out[2*s]:.2f} iters x {out[2*s]}" for s in range(3) if out[2 * s]))
 stats("warmup")
 for tag, over in (("deharsh", dict(deharsh=True)), ("punch", dict(addPunch=True)), ("glue", dict(glueCompression=True)),

@@ -25,6 +25,7 @@ void set_error(const char* fmt, ...) {
 Tuning& tuning() { static Tuning t; return t; }
 #ifdef WAM_COUNT_ITERS
 __device__ unsigned long long g_iter_stats[8];
+__device__ unsigned long long g_iter_hist[4];
 #endif
 
 // ---- workspace pool -----------------------------------------------------------
@@ -152,7 +153,10 @@ int wam_debug_counters(uint64_t out[8], int reset) {
 #ifdef WAM_COUNT_ITERS
   WAM_HIP(hipDeviceSynchronize());
   WAM_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(wam::g_iter_stats), sizeof(uint64_t) * 8));
-  if (reset) { uint64_t z[8] = {0}; WAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wam::g_iter_stats), z, sizeof(z))); }
+  uint64_t h[4];                       // the unused half of out[] (sites 3 would be [6], [7]) carries the pair histogram
+  WAM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(wam::g_iter_hist), sizeof(h)));
+  out[6] = h[0] << 32 | (h[1] & 0xffffffffull); out[7] = h[2] << 32 | (h[3] & 0xffffffffull);
+  if (reset) { uint64_t z[8] = {0}; WAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wam::g_iter_stats), z, sizeof(z))); WAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wam::g_iter_hist), z, sizeof(h))); }
 #endif
   return WAM_OK;
 }

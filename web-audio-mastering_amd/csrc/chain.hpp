@@ -22,6 +22,7 @@ struct ClipPlan {              // stage 9, soft-clipper.js:165-294
 struct LimiterPlan {           // stage 10, dsp-worker.js:286-452
   double ceil_lin, knee_db, knee_start, rc, rcC, pa, pr;
   int L, W, preserve;
+  int lib_twin;                // 1: the soft-knee pass of web/lib/dsp/limiter.js:81-128 (running maximum starts at 0, not at |y2|)
 };
 
 struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.js, multiband-transient.js

@@ -389,11 +389,12 @@ int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double 
   return st.down(st.out.as<float>(), out, nullptr);
 }
 
-int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
-                double knee_db, int preserve_transients, float* const* out) {
+static int limiter_entry(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
+                         double knee_db, int preserve_transients, float* const* out, int lib_twin) {
   int rc = check_io(ch, nch, n, out); if (rc) return rc;
   if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
   LimiterPlan lp; rc = make_limiter_plan(sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients != 0, &lp); if (rc) return rc;
+  lp.lib_twin = lib_twin;
   rc = ensure_device(); if (rc) return rc;
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
   DevBuf plan, genv, tm; rc = upload_plan(lp, plan, nullptr); if (rc) return rc;
@@ -403,6 +404,14 @@ int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ce
                        preserve_transients != 0, nullptr, nullptr, 0, nullptr, sr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
+}
+int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
+                double knee_db, int preserve_transients, float* const* out) {
+  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 0);
+}
+int wam_limiter_lib(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
+                    double knee_db, int preserve_transients, float* const* out) {
+  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 1);
 }
 
 static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int which, float* const* out) {

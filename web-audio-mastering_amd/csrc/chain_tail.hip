@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
       const double y3 = s[k];
       double r = y3;
       if (base + k >= 3) {
-        const double m = true_peak4(y0, y1, y2, y3);
+        const double m = P.lib_twin ? interp_peak3(y0, y1, y2, y3) : true_peak4(y0, y1, y2, y3);
         if (m > P.ceil_lin) r = y3 * (P.ceil_lin / m);
       }
       o[k] = f32r(soft_knee_curve(r, P.ceil_lin, P.knee_start));

@@ -308,6 +308,7 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
 // [2 site] = solves, [2 site + 1] = iterations; site 0 follower, 1 follower pair, 2 release smoother.
 #ifdef WAM_COUNT_ITERS
 extern __device__ unsigned long long g_iter_stats[8];
+extern __device__ unsigned long long g_iter_hist[4];     // follower pair: solves that took <= 2, 3, 4, > 4 iterations
 __device__ __forceinline__ void count_iters(int site, int iters) {
   if (threadIdx.x == 0) { atomicAdd(&g_iter_stats[2 * site], 1ull); atomicAdd(&g_iter_stats[2 * site + 1], (unsigned long long)iters); }
 }
@@ -379,7 +380,8 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
                                                 double* lds, double& start1, double& start2) {
   const int lane = lane_id(), wave = wave_id();
   const double S1_in = S1, S2_in = S2;
-  double s1 = S1, s2 = S2, p1 = S1, p2 = S2;
+  double s1 = S1, s2 = S2;
+  double p1 = s1, p2 = s2;
   int it = 0;
   for (; it < 260; it++) {
     double al1 = 1, be1 = 0, al2 = 1, be2 = 0;
@@ -419,6 +421,9 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
     s1 = n1; s2 = n2;
   }
   count_iters(1, it + 1);
+#ifdef WAM_COUNT_ITERS
+  if (threadIdx.x == 0) { const int h = it + 1 <= 2 ? 0 : (it + 1 == 3 ? 1 : (it + 1 == 4 ? 2 : 3)); atomicAdd(&g_iter_hist[h], 1ull); }
+#endif
   start1 = s1; start2 = s2;
 }
 
@@ -536,6 +541,16 @@ __device__ __forceinline__ double true_peak4(double y0, double y1, double y2, do
   pk = fmax(pk, fabs(((a0 * 0.25 + a1) * 0.25 + a2) * 0.25 + y1));
   pk = fmax(pk, fabs(((a0 * 0.5 + a1) * 0.5 + a2) * 0.5 + y1));
   pk = fmax(pk, fabs(((a0 * 0.75 + a1) * 0.75 + a2) * 0.75 + y1));
+  return pk;
+}
+// the three interpolated points only, in interpolateCatmullRom's form (utils.js:143-153; limiter.js:107-116)
+__device__ __forceinline__ double interp_peak3(double y0, double y1, double y2, double y3) {
+  const double a0 = -0.5 * y0 + 1.5 * y1 - 1.5 * y2 + 0.5 * y3;
+  const double a1 = y0 - 2.5 * y1 + 2 * y2 - 0.5 * y3;
+  const double a2 = -0.5 * y0 + 0.5 * y2;
+  double pk = fabs(a0 * 0.015625 + a1 * 0.0625 + a2 * 0.25 + y1);
+  pk = fmax(pk, fabs(a0 * 0.125 + a1 * 0.25 + a2 * 0.5 + y1));
+  pk = fmax(pk, fabs(a0 * 0.421875 + a1 * 0.5625 + a2 * 0.75 + y1));
   return pk;
 }
 __device__ __forceinline__ double catmull_half(double y0, double y1, double y2, double y3) {   // utils.js:143-153 at t = 0.5

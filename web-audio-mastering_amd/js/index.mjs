@@ -81,8 +81,9 @@ export function normalizeToLUFS(audioBuffer, targetLUFS = -14, ceilingDB = -1, o
   return gained;
 }
 export function applyLookaheadLimiter(audioBuffer, ceilingLinear = 0.891, lookaheadMs = 3, releaseMs = 100, kneeDB = 3, preserveTransients = true) {
-  // the worker twin (dsp-worker.js:286); the lib twin differs in one seed value (SURVEY.md 0.4)
-  return stage('limiter', audioBuffer, [ceilingLinear, lookaheadMs, releaseMs, kneeDB, preserveTransients ? 1 : 0]);
+  // web/lib/dsp/limiter.js:155 - the library twin (the worker's, behind DSPWorkerInterface.applyLimiter and the chain, seeds its
+  // soft-knee pass differently: SURVEY.md 0.4)
+  return stage('limiterLib', audioBuffer, [ceilingLinear, lookaheadMs, releaseMs, kneeDB, preserveTransients ? 1 : 0]);
 }
 export function applyMasteringSoftClip(audioBuffer, options = {}) {                  // soft-clipper.js:165
   const { ceiling = -1, lookaheadMs = 0.5, releaseMs = 10, drive = 1.5 } = options;

@@ -241,6 +241,7 @@ Job* job_stage(napi_env env, napi_value* a) {
     if (nm == "finalFilters") return wam_final_filters(p.data(), nch, j.in.n, sr, q[0] != 0, q[1] != 0, o.data());
     if (nm == "softClip") return wam_soft_clip(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], o.data());
     if (nm == "limiter") return wam_limiter(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], q[4] != 0, o.data());
+    if (nm == "limiterLib") return wam_limiter_lib(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], q[4] != 0, o.data());
     if (nm == "glue") return wam_glue_compressor(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], o.data());
     if (nm == "stereo") return wam_stereo(p.data(), j.in.n, sr, q[0], q[1] != 0, q[2], o.data());
     if (nm == "eq") return wam_parametric_eq(p.data(), nch, j.in.n, sr, q, q[5] != 0, o.data());

@@ -244,8 +244,9 @@ def apply_parametric_eq(chans, sr, gains, cut_mud=False):
     return _stage(lib().wam_parametric_eq, chans, C.c_double(sr), g, C.c_int(int(cut_mud)))
 
 
-def apply_lookahead_limiter(chans, sr, ceiling_linear, lookahead_ms=3.0, release_ms=100.0, knee_db=3.0, preserve_transients=True):
-    return _stage(lib().wam_limiter, chans, C.c_double(sr), C.c_double(ceiling_linear), C.c_double(lookahead_ms), C.c_double(release_ms),
+def apply_lookahead_limiter(chans, sr, ceiling_linear, lookahead_ms=3.0, release_ms=100.0, knee_db=3.0, preserve_transients=True, twin="worker"):
+    """twin="worker": applyLookaheadLimiterToChannels (dsp-worker.js:286); twin="lib": applyLookaheadLimiter (web/lib/dsp/limiter.js:155)"""
+    return _stage(lib().wam_limiter_lib if twin == "lib" else lib().wam_limiter, chans, C.c_double(sr), C.c_double(ceiling_linear), C.c_double(lookahead_ms), C.c_double(release_ms),
                   C.c_double(knee_db), C.c_int(int(preserve_transients)))
 
 
