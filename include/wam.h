@@ -107,6 +107,15 @@ int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample
 int wam_lufs_series(const float* const* ch, int nch, int64_t n, double sample_rate, const double* positions, int npos,
                     int momentary, double* lufs);
 
+/* resampleAudioBuffer(sourceBuffer, targetSampleRate), web/ui/renderer.js:172-187.  The reference renders the buffer through
+ * Chromium's OfflineAudioContext at the target rate; that engine is not in the image and the reference holds no fixtures of
+ * its output, so this entry is PARITY UNPINNED and self-defined: out[i] is the signal at source position i * src / dst
+ * (zero outside the buffer), quality 0 = linear interpolation, 1 = Kaiser-windowed sinc (cutoff 0.98 x the lower Nyquist
+ * rate, 64 zero crossings per side, beta 8.6).  n_out must equal wam_resample_length() = ceil(n / src * dst) (:178). */
+int64_t wam_resample_length(int64_t n, double src_rate, double dst_rate);
+int wam_resample(const float* const* ch, int nch, int64_t n, double src_rate, double dst_rate, int quality,
+                 float* const* out, int64_t n_out);
+
 /* extractPeaks(audioBuffer, numPeaks), web/ui/waveform.js:164-181: peaks[i] = max |x| over window i of floor(n / num_peaks)
  * samples of channel 0 (the values are f32 magnitudes, exact); all zero when n < num_peaks. */
 int wam_extract_peaks(const float* ch0, int64_t n, int num_peaks, float* peaks);

@@ -24,7 +24,7 @@ function track(c) {
 }
 
 async function cpu() {
-  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
+  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'resampleAudioBuffer', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
     'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
@@ -77,6 +77,14 @@ async function gpu() {
     const p = S['peaks_full']; const pab = track({ idx: p.idx, nch: p.nch, n: p.n_synth, sr: p.sr, opts: p.opts });
     const pk = wam.extractPeaks(pab, p.num_peaks), want = f32(p.peaks);
     ok(Array.isArray(pk) && pk.length === want.length && pk.every((v, i) => v === want[i]), 'extractPeaks identical'); }
+  // sample-rate conversion (self-defined, unpinned): length rule of renderer.js:178, early return, a sine stays a sine
+  { const sr = 48000, n = 24000; const ab = new wam.WamAudioBuffer({ numberOfChannels: 1, length: n, sampleRate: sr });
+    const x = ab.getChannelData(0); for (let i = 0; i < n; i++) x[i] = 0.5 * Math.sin(2 * Math.PI * 1000 * i / sr);
+    ok(await wam.resampleAudioBuffer(ab, sr) === ab && await wam.resampleAudioBuffer(ab, 0) === ab, 'resample early return');
+    const r = await wam.resampleAudioBuffer(ab, 44100);
+    ok(r.sampleRate === 44100 && r.length === Math.ceil(ab.duration * 44100), 'resample length');
+    let e = 0; const y = r.getChannelData(0); for (let i = 300; i < r.length - 300; i++) e = Math.max(e, Math.abs(y[i] - 0.5 * Math.sin(2 * Math.PI * 1000 * i / 44100)));
+    ok(e <= 2e-5, `resampled sine error ${e}`); }
   // the library twins: applyLookaheadLimiter (limiter.js:155) and normalizeToLUFS with / without its limiter branch (normalizer.js:38)
   { const L = JSON.parse(fs.readFileSync(path.join(DATA, 'libtwin.json'), 'utf8')).cases;
     for (const name of ['lib_limiter_hot', 'lib_limiter_mono']) {

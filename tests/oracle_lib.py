@@ -310,3 +310,30 @@ def render_chain(chans, sr, settings, mode="export"):
     res = Result()
     lib().ora_render_chain(pin, C.c_int(len(chans)), C.c_int64(n), C.c_double(sr), C.byref(s), C.c_int(1 if mode == "export" else 0), pout, C.byref(res))
     return keep2, res
+
+
+def resample_ref(x, src_rate, dst_rate, quality):
+    """numpy float64 restatement of wam_resample's OWN definition (include/wam.h; the reference's resampler is Chromium's and
+    unpinned): position p = i * src / dst, zero outside the buffer; quality 0 linear, 1 Kaiser-windowed sinc (cutoff 0.98 x lower Nyquist, 64 zeros, beta 8.6)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    n_out = int(math.ceil((n / src_rate) * dst_rate))
+    p = np.arange(n_out, dtype=np.float64) * (src_rate / dst_rate)
+    xp = np.concatenate([x, [0.0, 0.0]])
+    if quality == 0:
+        k = np.floor(p).astype(np.int64)
+        f = p - k
+        k = np.minimum(k, n)
+        return ((1.0 - f) * xp[k] + f * xp[np.minimum(k + 1, n + 1)]).astype(np.float32)
+    fc = min(1.0, dst_rate / src_rate) * 0.98
+    H = 64 / fc
+    out = np.zeros(n_out)
+    i0b = np.i0(8.6)
+    for d in range(-int(math.ceil(H)) - 1, int(math.ceil(H)) + 2):
+        k = np.floor(p).astype(np.int64) + d
+        t = p - k
+        u = t / H
+        ok = (k >= 0) & (k <= n - 1) & (t >= -H) & (t <= H)          # k in [ceil(p - H), floor(p + H)]
+        w = np.where(u * u < 1.0, np.i0(8.6 * np.sqrt(np.maximum(0.0, 1.0 - u * u))) / i0b, 0.0)
+        out += np.where(ok, xp[np.clip(k, 0, n + 1)] * (fc * np.sinc(fc * t) * w), 0.0)
+    return out.astype(np.float32)

@@ -67,6 +67,12 @@ export function measureLUFSSeries(audioBuffer, positions, kind = 'short-term') {
 export function extractPeaks(audioBuffer, numPeaks = 800) {                          // ui/waveform.js:164 (channel 0, plain number[])
   return Array.from(addon().extractPeaks([audioBuffer.getChannelData(0)], numPeaks));
 }
+// ui/renderer.js:172-187.  The reference renders through Chromium's OfflineAudioContext; here: a self-defined windowed-sinc
+// (options.quality 'sinc', default) or linear ('linear') conversion - parity unpinned (include/wam.h).  Same early return.
+export async function resampleAudioBuffer(sourceBuffer, targetSampleRate, options = {}) {
+  if (!sourceBuffer || !targetSampleRate || sourceBuffer.sampleRate === targetSampleRate) return sourceBuffer;
+  return makeAB(addon().resample(chansOf(sourceBuffer), sourceBuffer.sampleRate, targetSampleRate, options.quality === 'linear' ? 0 : 1), targetSampleRate);
+}
 export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
   return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
 }

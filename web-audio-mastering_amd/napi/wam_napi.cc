@@ -342,6 +342,18 @@ napi_value dc_offset(napi_env env, napi_callback_info info) {        // (channel
   if (remove) napi_set_named_property(env, o, "channels", make_channels(env, out));
   return o;
 }
+napi_value resample(napi_env env, napi_callback_info info) {         // (channels, srcRate, dstRate, quality 0|1) -> Float32Array[]   (renderer.js:172-187, unpinned)
+  napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  double src = 0, dst = 0; int32_t q = 1;
+  napi_get_value_double(env, a[1], &src); napi_get_value_double(env, a[2], &dst); if (argc >= 4) napi_get_value_int32(env, a[3], &q);
+  const int64_t n_out = wam_resample_length(in.n, src, dst);
+  std::vector<std::vector<float>> out(in.ch.size(), std::vector<float>((size_t)(n_out > 0 ? n_out : 0)));
+  std::vector<float*> op; for (auto& c : out) op.push_back(c.data());
+  auto p = in.ptrs();
+  if (wam_resample(p.data(), (int)p.size(), in.n, src, dst, q, op.data(), n_out)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  return make_channels(env, out);
+}
 napi_value extract_peaks(napi_env env, napi_callback_info info) {    // (channels, numPeaks) -> Float32Array   (waveform.js:164-181, channel 0)
   napi_value a[2]; size_t argc = 2; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
   Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
@@ -394,6 +406,7 @@ napi_value Init(napi_env env, napi_value exports) {
     {"stftDb", nullptr, stft_db, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"dcOffset", nullptr, dc_offset, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"extractPeaks", nullptr, extract_peaks, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"resample", nullptr, resample, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"lufsSeries", nullptr, lufs_series, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);

@@ -165,6 +165,18 @@ def lufs_series(chans, sr, positions, momentary=False):
     return out
 
 
+def resample(chans, src_rate, dst_rate, quality=1):
+    """resampleAudioBuffer - web/ui/renderer.js:172 (self-defined, parity unpinned: include/wam.h)"""
+    pin, keep = _ptrs(chans)
+    n = len(keep[0])
+    lib().wam_resample_length.restype = C.c_int64
+    n_out = lib().wam_resample_length(C.c_int64(n), C.c_double(src_rate), C.c_double(dst_rate))
+    outs = [np.empty(n_out, dtype=np.float32) for _ in keep]
+    pout = (FP * len(outs))(*[a.ctypes.data_as(FP) for a in outs])
+    _check(lib().wam_resample(pin, C.c_int(len(keep)), C.c_int64(n), C.c_double(src_rate), C.c_double(dst_rate), C.c_int(quality), pout, C.c_int64(n_out)))
+    return outs
+
+
 def extract_peaks(ch0, num_peaks=800):
     """extractPeaks(audioBuffer, numPeaks) - web/ui/waveform.js:164 (channel 0 only)"""
     x = np.ascontiguousarray(ch0, dtype=np.float32)
