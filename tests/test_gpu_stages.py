@@ -157,3 +157,11 @@ def test_limiter_lib_twin():
     a = wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], twin="lib")
     b = wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], twin="worker")
     assert maxerr(a, b) > 1e-4                 # the twins do differ where the soft-knee pass engages
+
+
+@pytest.mark.parametrize("sr,n,nch", [(44100, 50001, 2), (96000, 70003, 2), (48000, 30000, 1), (48000, 2047, 2), (48000, 2048 + 512, 1)])
+def test_deharsh_rates_and_shapes(sr, n, nch):
+    """De-harsh at other sample rates (band edges move), odd lengths (channel 1 is then not 8-byte aligned: the scalar load path),
+    mono, and lengths around one frame (no frame at all / exactly one)."""
+    x = O.synth(13, nch, n, sr, {"amp": 2.0, "clickAmp": 0.6})
+    assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= TOL
