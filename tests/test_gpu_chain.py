@@ -151,3 +151,18 @@ def test_batch_render_dev_matches_single():
         assert res[t].lufs == r.lufs and res[t].true_peak_db == r.true_peak_db
         yo, ro = O.render_chain(tracks[t], sr, s, "export")
         assert maxerr(host[t], yo) <= PCM_TOL
+
+
+def test_host_batch_equals_single():
+    """wam_batch_render (host pointers, up to eight staging threads on their own streams, groups of 8): 70 tracks = 9 groups, the
+    last one partial; every track equals its single-track render bit for bit, results included."""
+    sr, n = 48000, 20000
+    s = dict(wam.DEFAULT_SETTINGS, glueCompression=True)
+    tracks = [O.synth(100 + t, 2, n, sr, {"amp": 1.2 + 0.01 * t, "clickAmp": 0.5}) for t in range(70)]
+    outs, res = wam.batch_render(tracks, sr, s, "export")
+    for t in (0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 69):
+        y, r = wam.render_full_chain(tracks[t], sr, s, "export")
+        assert all(np.array_equal(a, b) for a, b in zip(outs[t], y)), t
+        assert res[t].lufs == r.lufs and res[t].true_peak_db == r.true_peak_db
+    with pytest.raises(wam.WamError):
+        wam.batch_render(tracks[:2], 0.0, s, "export")

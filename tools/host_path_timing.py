@@ -16,3 +16,16 @@ for name, fn in (("render_full_chain", lambda: wam.render_full_chain(x, sr, s, "
     for _ in range(k): fn()
     dt = (time.perf_counter() - t0) / k
     print(f"{name}: {dt * 1e3:.1f} ms per 3-min track incl. H2D/D2H from pageable host memory = {180 / dt:.0f} x realtime")
+
+# the host-pointer batch (two staging threads, copies of one group overlap the other group's kernels)
+T = 128
+xb = torch.empty((T, 2, n), dtype=torch.float32, device="cuda")
+bench.synth_dev(xb, T, 0, {"amp": 1.6, "clickAmp": 0.6})
+host = xb.cpu().numpy()
+del xb
+tracks = [[host[t, 0], host[t, 1]] for t in range(T)]
+wam.batch_render(tracks[:4], sr, s, "export")
+t0 = time.perf_counter()
+wam.batch_render(tracks, sr, s, "export")
+dt = time.perf_counter() - t0
+print(f"batch_render: {T} tracks in {dt * 1e3:.0f} ms incl. H2D/D2H from pageable host memory = {T * 180 / dt:.0f} x realtime")

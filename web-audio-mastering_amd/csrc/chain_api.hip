@@ -2,8 +2,11 @@
 // double with the host libm), the single-stage C ABI entry points and the
 // RENDER_FULL_CHAIN driver (dsp-worker.js:1468-1667) that strings the kernels together.
 #include "chain.hpp"
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <thread>
 
 namespace wam {
 
@@ -470,25 +473,57 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
   return render_batch_dev(in_dev, out_dev, ntracks, nch, n, sr, settings, mode, results, (hipStream_t)stream, nullptr, nullptr);
 }
 
+// Host-pointer batch.  Tracks go through the device in staging groups of 8; up to eight host threads, each with its own stream
+// and staging buffers, pull groups from a shared counter, so some groups' H2D / D2H copies run while other groups' kernels do
+// (copies from pageable memory are staged by the runtime and block their thread: 1 thread moves ~18 GB/s, 8 threads ~35 GB/s
+// against 221 ms of kernels per 128 tracks).  Results are independent of the split: tracks never interact.
 int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
                      float* const* out, wam_result* results) {
   if (!in || !out || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
+  for (int64_t i = 0; i < (int64_t)ntracks * nch; i++) if ((!in[i] || !out[i]) && n > 0) { set_error("channel pointer %lld is NULL", (long long)i); return WAM_ERR_INVALID; }
   int rc = ensure_device(); if (rc) return rc;
+  int device = 0; WAM_HIP(hipGetDevice(&device));
   const size_t per = (size_t)nch * (size_t)(n > 0 ? n : 1);
-  const int group = 64;                               // host staging group
-  DevBuf din, dout;
-  rc = din.alloc(sizeof(float) * per * group); if (rc) return rc;
-  rc = dout.alloc(sizeof(float) * per * group); if (rc) return rc;
-  for (int t0 = 0; t0 < ntracks; t0 += group) {
-    const int g = ntracks - t0 < group ? ntracks - t0 : group;
-    for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
-      WAM_HIP(hipMemcpyAsync(din.as<float>() + ((size_t)t * nch + c) * n, in[(size_t)(t0 + t) * nch + c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, nullptr));
-    rc = render_batch_dev(din.as<float>(), dout.as<float>(), g, nch, n, sr, settings, mode, results ? results + t0 : nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
-      WAM_HIP(hipMemcpyAsync(out[(size_t)(t0 + t) * nch + c], dout.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, nullptr));
-    WAM_HIP(hipStreamSynchronize(nullptr));
-  }
+  const int group = 8;                                // tracks per staging group
+  const int ngroups = (ntracks + group - 1) / group;
+  const int nworkers = ngroups < 8 ? ngroups : 8;
+  std::atomic<int> next{0};
+  std::vector<int> rcs(nworkers, WAM_OK);
+  std::vector<std::string> errs(nworkers);
+  auto worker = [&](int w) {
+    auto fail = [&](int code) { rcs[w] = code; errs[w] = wam_last_error(); next.store(ngroups); };   // error strings are per thread
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return fail(WAM_ERR_NO_DEVICE); }
+    if (wam_init(device) != WAM_OK) return fail(WAM_ERR_NO_DEVICE);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(WAM_ERR_HIP); }
+    auto body = [&]() -> int {
+      DevBuf din, dout;
+      int r = din.alloc(sizeof(float) * per * group); if (r) return r;
+      r = dout.alloc(sizeof(float) * per * group); if (r) return r;
+      for (;;) {
+        const int gi = next.fetch_add(1);
+        if (gi >= ngroups) break;
+        const int t0 = gi * group, g = ntracks - t0 < group ? ntracks - t0 : group;
+        for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
+          WAM_HIP(hipMemcpyAsync(din.as<float>() + ((size_t)t * nch + c) * n, in[(size_t)(t0 + t) * nch + c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+        r = render_batch_dev(din.as<float>(), dout.as<float>(), g, nch, n, sr, settings, mode, results ? results + t0 : nullptr, st, nullptr, nullptr);
+        if (r) return r;
+        for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
+          WAM_HIP(hipMemcpyAsync(out[(size_t)(t0 + t) * nch + c], dout.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+        WAM_HIP(hipStreamSynchronize(st));
+      }
+      return WAM_OK;
+    };
+    const int r = body();
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    if (r) fail(r);
+  };
+  std::vector<std::thread> extra;
+  for (int w = 1; w < nworkers; w++) extra.emplace_back(worker, w);
+  worker(0);
+  for (auto& t : extra) t.join();
+  for (int w = 0; w < nworkers; w++) if (rcs[w]) { set_error("%s", errs[w].c_str()); return rcs[w]; }
   return WAM_OK;
 }
 

@@ -330,6 +330,21 @@ def stft_db(chans, sr, nfft=4096, hop=1024, columns=False):
     return (out, cols) if columns else out
 
 
+def batch_render(tracks, sr, settings, mode="export"):
+    """wam_batch_render: host-pointer batch; tracks = list of tracks, each a list of nch float32 arrays of one common length.
+    Returns (outputs in the same shape, results)."""
+    nch, n = len(tracks[0]), len(tracks[0][0])
+    keep = [np.ascontiguousarray(c, dtype=np.float32) for t in tracks for c in t]
+    outs = [np.empty(n, dtype=np.float32) for _ in keep]
+    pin = (FP * len(keep))(*[a.ctypes.data_as(FP) for a in keep])
+    pout = (FP * len(outs))(*[a.ctypes.data_as(FP) for a in outs])
+    s = settings if isinstance(settings, Settings) else Settings.from_js(settings)
+    res = (Result * len(tracks))()
+    _check(lib().wam_batch_render(pin, C.c_int(len(tracks)), C.c_int(nch), C.c_int64(n), C.c_double(sr), C.byref(s),
+                                  C.c_int(1 if mode == "export" else 0), pout, res))
+    return [outs[i * nch:(i + 1) * nch] for i in range(len(tracks))], res
+
+
 # ---- device-resident batch (pointers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
 def batch_meter_dev(in_ptr, ntracks, nch, n, sr, fallback=-14.0, stream=0):
     l = (C.c_double * ntracks)()
