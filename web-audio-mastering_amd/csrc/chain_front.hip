@@ -131,8 +131,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         e = follower_step(e, (double)a[k], P.glue_A, P.glue_R);
         float g = 1.0f;
         if (e > P.glue_thr) {
-          // 10^(-(20 log10(e/thr)) (1 - 1/ratio) / 20) = (e/thr)^-(1 - 1/ratio); stored to a Float32Array by the reference
-          g = exp2f(-(float)P.glue_k * log2f((float)(e / P.glue_thr)));
+          // 10^(-(20 log10(e/thr)) (1 - 1/ratio) / 20) = (e/thr)^-(1 - 1/ratio); stored to a Float32Array by the reference.
+          // Evaluated to ~1e-15: a float32 intrinsic (1 ulp of the store) is enough for this stage alone, but the soft clipper
+          // downstream multiplies a one-ulp difference by up to ~550 (tools/hot_margin.py: 4e-5 on hot material).
+          g = f32r(pow_fast(e / P.glue_thr, -P.glue_k));
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) w[c][k] = f32r((double)w[c][k] * (double)g);
