@@ -363,28 +363,33 @@ __device__ __forceinline__ void count_iters(int, int) {}
 // guessed start value with a functor
 //     run(start, al, be, mask)
 // that returns the affine map (al, be) its chunk composes to UNDER THE BRANCHES IT
-// TOOK and a bitmask of those branches.  The maps are scanned for the start values
+// TOOK and a bitmask of those branches (equal masks must imply equal maps).  The maps are scanned for the start values
 // that policy implies; the loop repeats until no thread's mask changes, at which
 // point start values, branches and maps are mutually consistent = the sequential
 // solution.  Returns this thread's start value; S = tile carry in/out.
-template <bool CLAMP1 = false, class Run>
+// EXACT_GUESS: the caller's first guess is often the solution itself (release smoother on a tile without resets); then the
+// first scan's result is compared with it, which ends such a tile after one pass instead of two.
+template <bool CLAMP1 = false, bool EXACT_GUESS = false, class Run>
 __device__ __forceinline__ double solve_piecewise(Run run, double guess, double& S, double* lds, int max_iter = 260) {
   const double S_in = S;
   double start = guess, prev = guess;
+  unsigned pm = 0;
   int it = 0;
   for (; it < max_iter; it++) {
     double al, be;
-    run(start, al, be);
+    unsigned m;
+    run(start, al, be, m);
+    // Same branches as in the previous pass = same maps = the scan would reproduce the start values this pass ran from:
+    // they are the solution and S already holds the carry of that scan.  (The vote is also the barrier that lets lds be
+    // rewritten.)
+    if (it > 0 && !__syncthreads_or((int)(m != pm))) break;
+    pm = m;
     double Sc = S_in;
     const double ns = scan_affine<CLAMP1>(al, be, Sc, lds);
-    // Fixed point: the maps composed under this iteration's branches reproduce the start values they
-    // were run from, so branches, maps and start values are mutually consistent.  (Comparing bit
-    // patterns: identical maps scan to identical values.)
-    const int changed = __syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(start));   // also fences the reuse of lds
     S = Sc;
-    if (!changed) { start = ns; break; }
+    if (EXACT_GUESS && it == 0 && !__syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(start))) { start = ns; break; }
     // A comparison that is a tie to the last bit can flip with the ulp its own flip causes: a 2-cycle between two
-    // start vectors that are both valid to rounding.  Detected from the 4th iteration on (one more vote), then ended.
+    // start vectors that are both valid to rounding.  Detected from the 4th pass on (one more vote), then ended.
     if (it >= 3 && !__syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(prev))) { start = ns; break; }
     prev = start;
     start = ns;
@@ -400,13 +405,15 @@ template <class T>
 __device__ __forceinline__ double follower_solve(const T a[C], double A, double R, double& S, double* lds) {
   // (al, be) are functions of the branch pattern only (never of e0's low bits), so the fixed-point test of
   // solve_piecewise terminates as soon as the pattern is stable.  The envelope itself is materialised by follower_step.
-  auto run = [&](double e0, double& al, double& be) {
-    al = 1; be = 0;
+  auto run = [&](double e0, double& al, double& be, unsigned& m) {
+    al = 1; be = 0; m = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double e = fma(al, e0, be);
       const double an = (double)a[n];
-      const double c = (an > e) ? A : R;
+      const bool up = an > e;
+      const double c = up ? A : R;
+      m = (m << 1) | (unsigned)up;
       be = fma(c, be - an, an);              // = c be + (1 - c) a
       al = c * al;
     }
@@ -422,18 +429,75 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
   const int lane = lane_id(), wave = wave_id();
   const double S1_in = S1, S2_in = S2;
   double s1 = S1, s2 = S2;
+#ifndef WAM_NO_F32_PRESOLVE
+  // The first passes only have to get the branch pattern roughly right: they run in packed single precision (both
+  // followers in one v_pk_* instruction, half the shuffles) and need no convergence vote.  The double-precision loop below
+  // starts from their result and still ends only when its own start values reproduce themselves bit for bit, so the
+  // answer is unchanged.
+  {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f A = { (float)A1, (float)A2 }, R = { (float)R1, (float)R2 }, Sin = { (float)S1, (float)S2 };
+    v2f st = Sin;
+#pragma unroll 1
+    for (int pre = 0; pre < 2; pre++) {
+      v2f al = { 1.0f, 1.0f }, be = { 0.0f, 0.0f };
+#pragma unroll
+      for (int n = 0; n < C; n++) {
+        const float anf = (float)a[n];
+        const v2f an = { anf, anf };
+        const v2f e = al * st + be;
+        v2f c;
+        c.x = (anf > e.x) ? A.x : R.x;
+        c.y = (anf > e.y) ? A.y : R.y;
+        be = c * (be - an) + an;
+        al = c * al;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int d = 1 << k;
+        v2f ta, tb;
+        ta.x = __shfl_up(al.x, d); ta.y = __shfl_up(al.y, d); tb.x = __shfl_up(be.x, d); tb.y = __shfl_up(be.y, d);
+        if (lane >= d) { be = al * tb + be; al = al * ta; }
+      }
+      float* ldsf = (float*)lds;
+      if (lane == 63) { ldsf[4 * wave] = al.x; ldsf[4 * wave + 1] = al.y; ldsf[4 * wave + 2] = be.x; ldsf[4 * wave + 3] = be.y; }
+      v2f xa, xb;
+      xa.x = __shfl_up(al.x, 1); xa.y = __shfl_up(al.y, 1); xb.x = __shfl_up(be.x, 1); xb.y = __shfl_up(be.y, 1);
+      if (lane == 0) { xa = (v2f){ 1.0f, 1.0f }; xb = (v2f){ 0.0f, 0.0f }; }
+      __syncthreads();
+      v2f w = Sin, my = Sin;
+#pragma unroll
+      for (int k = 0; k < kWaves; k++) {
+        const v2f wa = { ldsf[4 * k], ldsf[4 * k + 1] }, wb = { ldsf[4 * k + 2], ldsf[4 * k + 3] };
+        w = wa * w + wb;
+        if (k + 1 == wave) my = w;
+      }
+      st = xa * my + xb;
+      __syncthreads();                                            // lds is rewritten by the next pass
+    }
+    s1 = (double)st.x; s2 = (double)st.y;
+  }
+#endif
   double p1 = s1, p2 = s2;
+  unsigned pm = 0;                                                // branch pattern of the previous pass, 2 bits per sample
   int it = 0;
   for (; it < 260; it++) {
     double al1 = 1, be1 = 0, al2 = 1, be2 = 0;
+    unsigned m = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double an = (double)a[n];
       const double e1 = fma(al1, s1, be1), e2 = fma(al2, s2, be2);
-      const double c1 = (an > e1) ? A1 : R1, c2 = (an > e2) ? A2 : R2;
+      const bool up1 = an > e1, up2 = an > e2;
+      const double c1 = up1 ? A1 : R1, c2 = up2 ? A2 : R2;
+      m = (m << 2) | ((unsigned)up1 << 1) | (unsigned)up2;
       be1 = fma(c1, be1 - an, an); be2 = fma(c2, be2 - an, an);
       al1 = c1 * al1; al2 = c2 * al2;
     }
+    // Same pattern as in the previous pass = same maps = the scan would reproduce the start values this pass ran from:
+    // they are the solution, and S1 / S2 already hold the carries of that scan.  (Also the barrier that lets lds be rewritten.)
+    if (it > 0 && !__syncthreads_or((int)(m != pm))) break;
+    pm = m;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const int d = 1 << k;
@@ -452,11 +516,11 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
       if (k + 1 == wave) { my1 = w1; my2 = w2; }
     }
     const double n1 = xa1 * my1 + xb1, n2 = xa2 * my2 + xb2;
-    const int changed = __syncthreads_or((int)(__double_as_longlong(n1) != __double_as_longlong(s1)) | (int)(__double_as_longlong(n2) != __double_as_longlong(s2)));
     S1 = w1; S2 = w2;
-    if (!changed) { s1 = n1; s2 = n2; break; }
+    // A comparison that is a tie to the last bit can flip with the ulp its own flip causes: a 2-cycle between two start
+    // vectors that are both valid to rounding.  Detected from the 4th pass on (one vote), then ended.
     if (it >= 3 && !__syncthreads_or((int)(__double_as_longlong(n1) != __double_as_longlong(p1)) | (int)(__double_as_longlong(n2) != __double_as_longlong(p2)))) {
-      s1 = n1; s2 = n2; break;                                  // 2-cycle on a last-bit tie, see solve_piecewise
+      s1 = n1; s2 = n2; break;
     }
     p1 = s1; p2 = s2;
     s1 = n1; s2 = n2;
@@ -478,15 +542,19 @@ __device__ __forceinline__ double follower_step(double e, double a, double A, do
 // g[] = this chunk's raw gains (f32 values).  rcC = rc^C.  Returns the chunk's start value.
 __device__ __forceinline__ double release_solve(const float g[C], double rc, double rcC, double& S, double* lds) {
   const double orc = 1 - rc;
-  auto run = [&](double cur, double& al, double& be) {
-    bool reset = false;
+  // (mask: which samples reset.  After the first reset the walk no longer depends on the start value, so equal masks
+  // give equal maps.)
+  auto run = [&](double cur, double& al, double& be, unsigned& m) {
+    m = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double gn = (double)g[n];
-      if (gn < cur) { cur = gn; reset = true; }
+      const bool rs = gn < cur;
+      m = (m << 1) | (unsigned)rs;
+      if (rs) cur = gn;
       else { cur = rc * cur + orc * 1.0; cur = fmin(cur, 1.0); }
     }
-    if (reset) { al = 0; be = cur; } else { al = rcC; be = 1 - rcC; }
+    if (m) { al = 0; be = cur; } else { al = rcC; be = 1 - rcC; }
   };
   // first guess: pure release from the carry (exact when the tile has no reset)
   double guess = S;
@@ -496,7 +564,7 @@ __device__ __forceinline__ double release_solve(const float g[C], double rc, dou
     while (t) { if (t & 1) p *= b; b *= b; t >>= 1; }
     guess = 1 - p * (1 - S);
   }
-  return solve_piecewise<true>(run, guess, S, lds);
+  return solve_piecewise<true, true>(run, guess, S, lds);
 }
 __device__ __forceinline__ double release_step(double cur, double g, double rc) {
   if (g < cur) return g;
