@@ -459,7 +459,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
         ta.x = __shfl_up(al.x, d); ta.y = __shfl_up(al.y, d); tb.x = __shfl_up(be.x, d); tb.y = __shfl_up(be.y, d);
         if (lane >= d) { be = al * tb + be; al = al * ta; }
       }
-      float* ldsf = (float*)lds;
+      float* ldsf = (float*)lds + 16 * pre;                       // the slot's 16 doubles = two regions of 16 floats, one per pass
       if (lane == 63) { ldsf[4 * wave] = al.x; ldsf[4 * wave + 1] = al.y; ldsf[4 * wave + 2] = be.x; ldsf[4 * wave + 3] = be.y; }
       v2f xa, xb;
       xa.x = __shfl_up(al.x, 1); xa.y = __shfl_up(al.y, 1); xb.x = __shfl_up(be.x, 1); xb.y = __shfl_up(be.y, 1);
@@ -473,8 +473,8 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
         if (k + 1 == wave) my = w;
       }
       st = xa * my + xb;
-      __syncthreads();                                            // lds is rewritten by the next pass
     }
+    __syncthreads();                                              // the loop below rewrites the slot
     s1 = (double)st.x; s2 = (double)st.y;
   }
 #endif
