@@ -156,6 +156,22 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
                         double fallback, double* lufs, double* dbtp, void* stream);
 
+/* What web/app.js:823-872 does on every file load, as one call with one upload: detectDCOffsetBuffer
+ * (dc-offset.js:38-60); removeDCOffset on every channel when any channel's |mean| > 0.001 (app.js:828-834); measureLUFS and
+ * findTruePeak of the result (:865-866); normalizeToLUFS(buffer, target_lufs, ceiling_db) with the library limiter when the
+ * projected peak exceeds the ceiling (normalizer.js:38-94).  cleaned / normalized (either may be NULL) receive the buffer
+ * after DC removal (a copy of the input when none was needed) and the normalised buffer (the cleaned buffer when loudness
+ * is not finite, as the reference returns its input). */
+typedef struct wam_load_analysis {
+  double dc[2];                 /* mean per channel */
+  double dc_percent;            /* average |mean| * 100 (dcInfo.average.percent) */
+  double original_lufs, original_true_peak_db;
+  double gain_db;               /* applied by the normalisation (0 when not measured) */
+  int32_t dc_significant, dc_removed, measured, limiter_applied;
+} wam_load_analysis;
+int wam_analyze_on_load(const float* const* ch, int nch, int64_t n, double sample_rate, double target_lufs, double ceiling_db,
+                        float* const* cleaned, float* const* normalized, wam_load_analysis* res);
+
 /* applyGain(audioBuffer, gainDB), web/lib/dsp/normalizer.js:103-121: out = f32(in * 10^(gainDB/20)). */
 int wam_apply_gain(const float* const* ch, int nch, int64_t n, double gain_db, float* const* out);
 

@@ -24,7 +24,7 @@ function track(c) {
 }
 
 async function cpu() {
-  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'resampleAudioBuffer', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
+  for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'resampleAudioBuffer', 'analyzeOnLoad', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
     'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
@@ -77,6 +77,15 @@ async function gpu() {
     const p = S['peaks_full']; const pab = track({ idx: p.idx, nch: p.nch, n: p.n_synth, sr: p.sr, opts: p.opts });
     const pk = wam.extractPeaks(pab, p.num_peaks), want = f32(p.peaks);
     ok(Array.isArray(pk) && pk.length === want.length && pk.every((v, i) => v === want[i]), 'extractPeaks identical'); }
+  // the load-time bundle equals the separate calls the app makes (app.js:823-872)
+  { const c = golden['meter_10s_48k']; const ab = track(c);
+    const a = wam.analyzeOnLoad(ab, -14);
+    const dcInfo = wam.detectDCOffsetBuffer(ab);
+    ok(a.dcOffset.significant === dcInfo.significant && Math.abs(a.dcOffset.percent - dcInfo.average.percent) < 1e-9, 'analyzeOnLoad dc');
+    const base = a.dcOffset.removed ? a.originalBuffer : ab;
+    ok(Math.abs(a.originalLufs - wam.measureLUFS(base)) <= 1e-9 && Math.abs(a.originalTruePeak - wam.findTruePeak(base)) <= 1e-9, 'analyzeOnLoad meters');
+    const nrm = wam.normalizeToLUFS(base, -14);
+    ok(maxAbsDiff(a.normalizedBuffer.getChannelData(0), nrm.getChannelData(0)) === 0, 'analyzeOnLoad normalised buffer equals normalizeToLUFS'); }
   // sample-rate conversion (self-defined, unpinned): length rule of renderer.js:178, early return, a sine stays a sine
   { const sr = 48000, n = 24000; const ab = new wam.WamAudioBuffer({ numberOfChannels: 1, length: n, sampleRate: sr });
     const x = ab.getChannelData(0); for (let i = 0; i < n; i++) x[i] = 0.5 * Math.sin(2 * Math.PI * 1000 * i / sr);

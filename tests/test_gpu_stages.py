@@ -165,3 +165,34 @@ def test_deharsh_rates_and_shapes(sr, n, nch):
     mono, and lengths around one frame (no frame at all / exactly one)."""
     x = O.synth(13, nch, n, sr, {"amp": 2.0, "clickAmp": 0.6})
     assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= TOL
+
+
+def test_analyze_on_load():
+    """8f rank 2: the load-time bundle of web/app.js:823-872 in one call, against the same steps taken one by one on the oracle
+    (dc-offset.js, lufs.js, true-peak.js, normalizer.js with the library limiter; each of those steps is pinned on the reference's
+    own run in tests/test_oracle_golden.py)."""
+    sr, n = 48000, 30000
+    seen = set()
+    for dc, target in ((0.004, -9.0), (0.0, -9.0), (None, -9.0), (None, -30.0)):
+        x = O.synth(41, 2, n, sr, {"clickAmp": 0.5, "dc": dc or 0.0})
+        if dc is None:                                                        # centred: below the 0.001 threshold
+            x = [(c - np.float32(c.astype(np.float64).mean())).astype(np.float32) for c in x]
+        cleaned, normalized, r = wam.analyze_on_load(x, sr, target, -1.0)
+        means = [O.dc_detect(c) for c in x]
+        sig = any(abs(m) > 0.001 for m in means)
+        assert bool(r.dc_significant) == sig and bool(r.dc_removed) == sig
+        assert abs(r.dc_percent - sum(abs(m) for m in means) / 2 * 100) <= 1e-9
+        ref = [O.dc_remove(c)[1] for c in x] if sig else [c.copy() for c in x]
+        assert maxerr(cleaned, ref) <= 6e-8                                   # one f32 ulp where the mean's last bits differ
+        lufs, tp = O.measure_lufs(ref, sr), O.true_peak_db(ref)
+        assert abs(r.original_lufs - lufs) <= 1e-6 and abs(r.original_true_peak_db - tp) <= 1e-6
+        gain_db = target - lufs
+        gained = [(c.astype(np.float64) * 10 ** (gain_db / 20)).astype(np.float32) for c in ref]
+        want = O.limiter_lib(gained, sr, 10 ** (-1.0 / 20)) if tp + gain_db > -1.0 else gained
+        assert bool(r.limiter_applied) == (tp + gain_db > -1.0)
+        assert abs(r.gain_db - gain_db) <= 1e-6 and maxerr(normalized, want) <= TOL
+        seen.add((sig, bool(r.limiter_applied)))
+    assert (False, True) in seen and (True, True) in seen and (False, False) in seen     # every branch was taken
+    z = [np.zeros(20000, np.float32)] * 2
+    cl, nm, r = wam.analyze_on_load(z, sr)
+    assert not r.measured and r.original_lufs == -np.inf and np.array_equal(nm[0], z[0])

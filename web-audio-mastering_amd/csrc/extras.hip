@@ -3,6 +3,7 @@
 //   wam_normalize     normalizeChannelsToLUFS (NORMALIZE message)    web/workers/dsp-worker.js:457-527
 //   wam_encode_pcm24  encodeWAV 24-bit sample loop                   web/ui/encoder.js:92-124
 //   wam_wav_header    encodeWAV header                               web/ui/encoder.js:74-86
+//   wam_analyze_on_load  the load-time bundle: DC + LUFS + TP + normalizeToLUFS   web/app.js:823-872
 //   wam_resample      resampleAudioBuffer (unpinned: Chromium's engine)  web/ui/renderer.js:172-187
 //   wam_extract_peaks extractPeaks                                   web/ui/waveform.js:164-181
 //   wam_stft_db       Spectrogram.process / fft / updateLatestColumn web/ui/spectrogram.js:113-257, batched over frames
@@ -516,6 +517,84 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
   res->final_lufs = finish_lufs(mp14, g);
   res->peak_db = proj;
   for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpy(out[c], result + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return WAM_OK;
+}
+
+// The analysis the app runs on every file load (web/app.js:823-872), as one call with one upload: DC detection
+// (detectDCOffsetBuffer, dc-offset.js:38-60), removal from every channel when any channel is "significant" (:828-834), loudness
+// and true peak of the result (:865-866), and normalizeToLUFS(buffer, target) with the LIBRARY limiter when the projected peak
+// exceeds the ceiling (normalizer.js:38-94).
+int wam_analyze_on_load(const float* const* ch, int nch, int64_t n, double sr, double target_lufs, double ceiling_db,
+                        float* const* cleaned, float* const* normalized, wam_load_analysis* res) {
+  int rc = check_in(ch, nch, n); if (rc) return rc;
+  if (!res || !(sr > 0)) { set_error("invalid load-analysis arguments"); return WAM_ERR_INVALID; }
+  for (int c = 0; c < nch; c++) if (((cleaned && !cleaned[c]) || (normalized && !normalized[c])) && n > 0) { set_error("output channel %d is NULL", c); return WAM_ERR_INVALID; }
+  rc = ensure_device(); if (rc) return rc;
+  std::memset(res, 0, sizeof(*res));
+  if (n == 0) { res->dc[0] = res->dc[1] = NAN; res->original_lufs = -14.0; res->original_true_peak_db = -INFINITY; return WAM_OK; }
+  const size_t bytes = sizeof(float) * (size_t)n;
+  DevBuf in, cl, part, dcd, ms, nb, gd;
+  rc = upload_chans(ch, nch, n, in); if (rc) return rc;
+  // 1. DC offset
+  const int nparts = 256;
+  rc = part.alloc(sizeof(double) * nparts * nch); if (rc) return rc;
+  rc = dcd.alloc(sizeof(double) * nch); if (rc) return rc;
+  WAM_LAUNCH("k_dc_partial", k_dc_partial, dim3(nparts, nch), dim3(256), nullptr, (const float*)in.as<float>(), n, part.as<double>());
+  WAM_LAUNCH("k_dc_final", k_dc_final, dim3(nch), dim3(64), nullptr, (const double*)part.as<double>(), nparts, n, dcd.as<double>());
+  WAM_HIP(hipMemcpy(res->dc, dcd.p, sizeof(double) * nch, hipMemcpyDeviceToHost));
+  double tot = 0;
+  for (int c = 0; c < nch; c++) { tot += std::fabs(res->dc[c]); if (std::fabs(res->dc[c]) > 0.001) res->dc_significant = 1; }   // dc-offset.js:29,58
+  res->dc_percent = tot / nch * 100;                                                                                            // :50-56
+  const float* cur = in.as<float>();
+  if (res->dc_significant) {                                                                                                   // app.js:828-834
+    rc = cl.alloc(bytes * nch); if (rc) return rc;
+    int64_t bx = (n + 255) / 256; if (bx > 2048) bx = 2048;
+    WAM_LAUNCH("k_dc_sub", k_dc_sub, dim3((unsigned)bx, nch), dim3(256), nullptr, (const float*)in.as<float>(), cl.as<float>(), n, (const double*)dcd.as<double>());
+    cur = cl.as<float>();
+    res->dc_removed = 1;
+  }
+  if (cleaned) for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpyAsync(cleaned[c], cur + (size_t)c * n, bytes, hipMemcpyDeviceToHost, nullptr));
+  // 2. loudness and peak of the (cleaned) buffer; normalizeToLUFS measures again with fallback = target, which differs from
+  //    measureLUFS(buffer) only for audio shorter than 0.4 s
+  MeterPlan mp; rc = make_meter_plan(nch, n, sr, -14.0, &mp); if (rc) return rc;
+  rc = ms.alloc(meter_scratch_bytes(mp, 1, false)); if (rc) return rc;
+  MeterScratch M; carve_meter_scratch(mp, 1, false, ms.p, &M);
+  rc = enqueue_meter(cur, 1, mp, n, M, nullptr); if (rc) return rc;
+  GateOut g;
+  WAM_HIP(hipMemcpy(&g, M.gate, sizeof(g), hipMemcpyDeviceToHost));
+  res->original_lufs = finish_lufs(mp, g);
+  res->original_true_peak_db = finish_peak_db(g);
+  // 3. normalizeToLUFS(buffer, target, ceiling)
+  const double lufs_n = mp.too_short ? target_lufs : res->original_lufs;
+  if (!std::isfinite(lufs_n)) {                                                                                                // normalizer.js:44-47: the same buffer
+    if (normalized) for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpyAsync(normalized[c], cur + (size_t)c * n, bytes, hipMemcpyDeviceToHost, nullptr));
+    WAM_HIP(hipStreamSynchronize(nullptr));
+    return WAM_OK;
+  }
+  res->measured = 1;
+  res->gain_db = target_lufs - lufs_n;
+  const double gl = std::pow(10, res->gain_db / 20);
+  rc = nb.alloc(bytes * nch); if (rc) return rc;
+  rc = gd.alloc(sizeof(double)); if (rc) return rc;
+  WAM_HIP(hipMemcpy(gd.p, &gl, sizeof(double), hipMemcpyHostToDevice));
+  rc = enqueue_gain_meter(cur, nb.as<float>(), 1, nch, n, gd.as<double>(), mp, M, nullptr); if (rc) return rc;                  // (the meter by-product is not used)
+  const float* result = nb.as<float>();
+  DevBuf o, plan, tmb, gv;
+  if (res->original_true_peak_db + res->gain_db > ceiling_db) {                                                                 // :81-91, library limiter
+    LimiterPlan lp; rc = make_limiter_plan(sr, std::pow(10, ceiling_db / 20), 3, 100, 3, 1, &lp); if (rc) return rc;
+    lp.lib_twin = 1;
+    rc = plan.alloc(sizeof(lp)); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(plan.p, &lp, sizeof(lp), hipMemcpyHostToDevice, nullptr));
+    rc = tmb.alloc(bytes); if (rc) return rc;
+    rc = gv.alloc(bytes); if (rc) return rc;
+    rc = o.alloc(bytes * nch); if (rc) return rc;
+    rc = enqueue_limiter(nb.as<float>(), o.as<float>(), tmb.as<float>(), gv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L, 1,
+                         nullptr, nullptr, 0, nullptr, sr, nullptr); if (rc) return rc;
+    result = o.as<float>();
+    res->limiter_applied = 1;
+  }
+  if (normalized) for (int c = 0; c < nch; c++) WAM_HIP(hipMemcpyAsync(normalized[c], result + (size_t)c * n, bytes, hipMemcpyDeviceToHost, nullptr));
+  WAM_HIP(hipStreamSynchronize(nullptr));
   return WAM_OK;
 }
 

@@ -73,6 +73,16 @@ export async function resampleAudioBuffer(sourceBuffer, targetSampleRate, option
   if (!sourceBuffer || !targetSampleRate || sourceBuffer.sampleRate === targetSampleRate) return sourceBuffer;
   return makeAB(addon().resample(chansOf(sourceBuffer), sourceBuffer.sampleRate, targetSampleRate, options.quality === 'linear' ? 0 : 1), targetSampleRate);
 }
+// What web/app.js:823-872 does on every file load, in one call with one upload: DC check (+ removal when significant), loudness and
+// true peak of the result, normalizeToLUFS(buffer, targetLufs).  Returns the fields the app stores in fileState.
+export function analyzeOnLoad(decodedBuffer, targetLufs = -14, ceilingDB = -1) {
+  const r = addon().analyzeOnLoad(chansOf(decodedBuffer), decodedBuffer.sampleRate, targetLufs, ceilingDB);
+  const sr = decodedBuffer.sampleRate;
+  const originalBuffer = r.dcRemoved ? makeAB(r.cleaned, sr) : decodedBuffer;
+  return { dcOffset: { percent: r.dcPercent, removed: !!r.dcRemoved, significant: !!r.dcSignificant, channels: r.dc },
+    originalBuffer, originalLufs: r.originalLufs, originalTruePeak: r.originalTruePeak, originalSampleRate: sr,
+    normalizedBuffer: r.measured ? makeAB(r.normalized, sr) : originalBuffer, gainApplied: r.gainDb, limiterApplied: !!r.limiterApplied };
+}
 export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
   return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
 }

@@ -342,6 +342,25 @@ napi_value dc_offset(napi_env env, napi_callback_info info) {        // (channel
   if (remove) napi_set_named_property(env, o, "channels", make_channels(env, out));
   return o;
 }
+napi_value analyze_on_load(napi_env env, napi_callback_info info) {   // (channels, sampleRate, targetLufs, ceilingDb) -> {dc, dcPercent, ..., cleaned, normalized}   (app.js:823-872)
+  napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  double sr = 0, target = -14, ceiling = -1;
+  napi_get_value_double(env, a[1], &sr); if (argc >= 3) napi_get_value_double(env, a[2], &target); if (argc >= 4) napi_get_value_double(env, a[3], &ceiling);
+  std::vector<std::vector<float>> cl(in.ch.size(), std::vector<float>((size_t)in.n)), nm(in.ch.size(), std::vector<float>((size_t)in.n));
+  std::vector<float*> pc, pn; for (auto& c : cl) pc.push_back(c.data()); for (auto& c : nm) pn.push_back(c.data());
+  wam_load_analysis r; auto p = in.ptrs();
+  if (wam_analyze_on_load(p.data(), (int)p.size(), in.n, sr, target, ceiling, pc.data(), pn.data(), &r)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  napi_value o, arr; napi_create_object(env, &o); napi_create_array_with_length(env, in.ch.size(), &arr);
+  for (size_t c = 0; c < in.ch.size(); c++) { napi_value v; napi_create_double(env, r.dc[c], &v); napi_set_element(env, arr, (uint32_t)c, v); }
+  napi_set_named_property(env, o, "dc", arr);
+  set_num(env, o, "dcPercent", r.dc_percent); set_num(env, o, "originalLufs", r.original_lufs); set_num(env, o, "originalTruePeak", r.original_true_peak_db);
+  set_num(env, o, "gainDb", r.gain_db); set_num(env, o, "dcSignificant", r.dc_significant); set_num(env, o, "dcRemoved", r.dc_removed);
+  set_num(env, o, "measured", r.measured); set_num(env, o, "limiterApplied", r.limiter_applied);
+  napi_set_named_property(env, o, "cleaned", make_channels(env, cl));
+  napi_set_named_property(env, o, "normalized", make_channels(env, nm));
+  return o;
+}
 napi_value resample(napi_env env, napi_callback_info info) {         // (channels, srcRate, dstRate, quality 0|1) -> Float32Array[]   (renderer.js:172-187, unpinned)
   napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
   Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
@@ -407,6 +426,7 @@ napi_value Init(napi_env env, napi_value exports) {
     {"dcOffset", nullptr, dc_offset, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"extractPeaks", nullptr, extract_peaks, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"resample", nullptr, resample, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"analyzeOnLoad", nullptr, analyze_on_load, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"lufsSeries", nullptr, lufs_series, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);

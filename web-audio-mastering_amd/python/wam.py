@@ -200,6 +200,23 @@ def meter(chans, sr, fallback=-14.0):
     return l.value, t.value
 
 
+class LoadAnalysis(C.Structure):
+    _fields_ = [("dc", C.c_double * 2), ("dc_percent", C.c_double), ("original_lufs", C.c_double), ("original_true_peak_db", C.c_double),
+                ("gain_db", C.c_double), ("dc_significant", C.c_int32), ("dc_removed", C.c_int32), ("measured", C.c_int32),
+                ("limiter_applied", C.c_int32)]
+
+
+def analyze_on_load(chans, sr, target_lufs=-14.0, ceiling_db=-1.0):
+    """web/app.js:823-872 in one call: (cleaned, normalized, LoadAnalysis)"""
+    pin, keep = _ptrs(chans)
+    pc, cleaned = _outs(keep)
+    pn, normalized = _outs(keep)
+    res = LoadAnalysis()
+    _check(lib().wam_analyze_on_load(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(target_lufs), C.c_double(ceiling_db),
+                                     pc, pn, C.byref(res)))
+    return cleaned, normalized, res
+
+
 def dc_offset(chans, remove=False):
     """detectDCOffsetBuffer / removeDCOffset - web/lib/dsp/dc-offset.js:38,67"""
     pin, keep = _ptrs(chans)
