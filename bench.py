@@ -151,14 +151,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # WAM_BENCH_REHEARSAL=1: run the N-rank code path on a box with ONE GPU (all ranks on cuda:0, gloo for the three collectives);
+    # a correctness rehearsal of the sharding / gathering plumbing only - its numbers mean nothing.
+    rehearsal = os.environ.get("WAM_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not rehearsal) else 0)
+    comm = torch.device("cpu") if rehearsal else dev            # where the collectives' tensors live
     wam.init(dev.index)
 
     global SR, SECONDS, N
@@ -187,7 +195,9 @@ def main():
         return wam.batch_meter_dev(x.data_ptr(), T, NCH, N, SR)
 
     def barrier():
-        wam_dist.barrier(dev)
+        torch.cuda.synchronize(dev)
+        wam_dist.barrier(comm)
+        torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
@@ -201,7 +211,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = profile_read()
     wam.lib().wam_profile_enable(0)
-    dt = wam_dist.max_over_ranks(dt, dev)
+    dt = wam_dist.max_over_ranks(dt, comm)
     # per-track scalars of every shard, in global track order (the only data that leaves a rank)
     if chain_like:
         local = [[r.lufs, r.true_peak_db, r.lufs_in, r.gain_db] for r in res]
@@ -209,7 +219,7 @@ def main():
         local = [[float(spec[t].max()), float(spec[t, :, 1:].float().mean())] for t in range(min(T, 4))] + [[0.0, 0.0]] * max(0, T - 4)
     else:
         local = [[float(a), float(b)] for a, b in zip(res[0], res[1])]
-    table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64), world * T, dev)
+    table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64), world * T, comm)
 
     if rank == 0:
         audio_s = world * T * SECONDS * args.steps
@@ -246,7 +256,7 @@ def main():
                        "x realtime (audio-s/s) 4096-pt STFT hop 1024" if wl == "stft" else "x realtime (audio-s/s) LUFS+true-peak meter"),
             "value": audio_s / dt, "unit": "x realtime (audio-s/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, numbers meaningless)" if rehearsal else ""),
             "config": {"workload": ({"chain": f"BASELINE configs[2]: {T} tracks/GPU", "single": "BASELINE configs[1]: one track",
                                      "longform": "BASELINE configs[3]: one long-form track"}[wl] +
                                     f" x {SECONDS // 60}-min stereo {SR // 1000} kHz, full export chain "
