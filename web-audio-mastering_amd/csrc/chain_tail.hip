@@ -126,57 +126,67 @@ __global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__
                                                        const ClipPlan* __restrict__ cp, const double* __restrict__ gains,
                                                        const float* __restrict__ genv) {
   const ClipPlan& P = *cp;
-  const int64_t chan = blockIdx.y;
-  const int64_t trk = chan / nch;
+  const int64_t trk = blockIdx.y;                       // a block takes all channels of its chunk: the shared envelope is read once
   const double G = gains ? gains[trk] : 1.0;
-  const float* x = in + chan * n;
   const float* g = genv + trk * n;
-  float* y = out + chan * n;
   const double ceil_lin = P.ceil_lin;
   for (int64_t base = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * C; base < n; base += (int64_t)gridDim.x * kThreads * C) {
-    float xv[C + 3], gv[C + 3];        // samples base-1 .. base+C+1
+    float gv[C + 3];                   // envelope of samples base-1 .. base+C+1
     {
-      float v[C], w[C];
-      load_chunk(x, n, base, v);
+      float w[C];
       load_chunk(g, n, base, w);
 #pragma unroll
-      for (int k = 0; k < C; k++) { xv[k + 1] = v[k]; gv[k + 1] = w[k]; }
-      xv[0] = base - 1 >= 0 ? x[base - 1] : 0.0f; gv[0] = base - 1 >= 0 ? g[base - 1] : 1.0f;
-      xv[C + 1] = base + C < n ? x[base + C] : 0.0f; gv[C + 1] = base + C < n ? g[base + C] : 1.0f;
-      xv[C + 2] = base + C + 1 < n ? x[base + C + 1] : 0.0f; gv[C + 2] = base + C + 1 < n ? g[base + C + 1] : 1.0f;
+      for (int k = 0; k < C; k++) gv[k + 1] = w[k];
+      gv[0] = base - 1 >= 0 ? g[base - 1] : 1.0f;
+      gv[C + 1] = base + C < n ? g[base + C] : 1.0f;
+      gv[C + 2] = base + C + 1 < n ? g[base + C + 1] : 1.0f;
     }
-    double s[C + 3];
+    for (int c = 0; c < nch; c++) {
+      const float* x = in + (trk * nch + c) * n;
+      float* y = out + (trk * nch + c) * n;
+      float xv[C + 3];
+      {
+        float v[C];
+        load_chunk(x, n, base, v);
 #pragma unroll
-    for (int k = 0; k < C + 3; k++) {
-      const int64_t i = base - 1 + k;
-      double xi = (double)f32r((double)xv[k] * G);
-      double gi = gv[k];
-      if (i < 0 || i >= n) { xi = 0; gi = 1; }
-      if (!(xi == xi)) xi = 0;                      // input[k] || 0 for NaN (neighbours only; see below)
-      if (gi == 0 || !(gi == gi)) gi = 1;           // gainEnvelope[k] || 1
-      s[k] = xi * gi;
-    }
-    float o[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      // centre sample uses input[i] * gainEnvelope[i] without the || fallbacks (soft-clipper.js:242,249)
-      const double p2 = (double)f32r((double)xv[k + 1] * G), g2 = gv[k + 1];
-      double sA = p2 * g2;
-      double sB = catmull_half(s[k], p2 * g2, s[k + 2], s[k + 3]);
-      double v2[2] = { sA, sB };
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const double a = fabs(v2[q]);
-        if (a > ceil_lin) {
-          const double ex = (a - ceil_lin) / ceil_lin;
-          const double red = 1 - tanh_fast(ex * 2) * 0.1;
-          const double m = fmin(a * red, ceil_lin);
-          v2[q] = v2[q] > 0 ? m : -m;
-        }
+        for (int k = 0; k < C; k++) xv[k + 1] = v[k];
+        xv[0] = base - 1 >= 0 ? x[base - 1] : 0.0f;
+        xv[C + 1] = base + C < n ? x[base + C] : 0.0f;
+        xv[C + 2] = base + C + 1 < n ? x[base + C + 1] : 0.0f;
       }
-      o[k] = f32r((v2[0] + v2[1]) * 0.5);
+      double s[C + 3];
+#pragma unroll
+      for (int k = 0; k < C + 3; k++) {
+        const int64_t i = base - 1 + k;
+        double xi = (double)f32r((double)xv[k] * G);
+        double gi = gv[k];
+        if (i < 0 || i >= n) { xi = 0; gi = 1; }
+        if (!(xi == xi)) xi = 0;                      // input[k] || 0 for NaN (neighbours only; see below)
+        if (gi == 0 || !(gi == gi)) gi = 1;           // gainEnvelope[k] || 1
+        s[k] = xi * gi;
+      }
+      float o[C];
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        // centre sample uses input[i] * gainEnvelope[i] without the || fallbacks (soft-clipper.js:242,249)
+        const double p2 = (double)f32r((double)xv[k + 1] * G), g2 = gv[k + 1];
+        double sA = p2 * g2;
+        double sB = catmull_half(s[k], p2 * g2, s[k + 2], s[k + 3]);
+        double v2[2] = { sA, sB };
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const double a = fabs(v2[q]);
+          if (a > ceil_lin) {
+            const double ex = (a - ceil_lin) / ceil_lin;
+            const double red = 1 - tanh_fast(ex * 2) * 0.1;
+            const double m = fmin(a * red, ceil_lin);
+            v2[q] = v2[q] > 0 ? m : -m;
+          }
+        }
+        o[k] = f32r((v2[0] + v2[1]) * 0.5);
+      }
+      store_chunk(y, n, base, o);
     }
-    store_chunk(y, n, base, o);
   }
 }
 
@@ -462,8 +472,9 @@ int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int
   const unsigned nseg = (unsigned)((ntiles + seg - 1) / seg);
   if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
   else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
-  int64_t bx = (n + (int64_t)kThreads * C - 1) / ((int64_t)kThreads * C); if (bx > 64) bx = 64;
-  WAM_LAUNCH("k_sc_apply", k_sc_apply, dim3((unsigned)bx, (unsigned)(ntracks * nch)), dim3(kThreads), s, in, out, nch, n, plan_dev, gains_dev, (const float*)genv);
+  const int64_t cap = ntracks >= 32 ? 64 : 2048 / ntracks;      // ~2,048 workgroups however few the tracks
+  int64_t bx = (n + (int64_t)kThreads * C - 1) / ((int64_t)kThreads * C); if (bx > cap) bx = cap;
+  WAM_LAUNCH("k_sc_apply", k_sc_apply, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, out, nch, n, plan_dev, gains_dev, (const float*)genv);
   return WAM_OK;
 }
 
