@@ -190,7 +190,8 @@ int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, 
   const int64_t mw = meter_warm((int64_t)std::floor(sr * 0.1), sr) + 1;          // +1: the 30 Hz high-pass settles slower than the K-weighting
   const int64_t gw = scale_warm(tuning().glue_warm_tiles, sr);
   const int64_t warm = (do_glue && gw > mw) ? gw : mw;
-  const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().meter_seg_tiles);
+  // long warm-up (the glue follower's 50 tiles): as few segments as still fill the chip once (2 workgroups per CU resident)
+  const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().meter_seg_tiles, warm >= 16 ? 512 : 2048);
   const dim3 grid(ntracks, (unsigned)((ntiles + seg - 1) / seg));
   if (nch == 2) WAM_LAUNCH("k_front", k_front<2>, grid, dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain, seg, warm);
   else WAM_LAUNCH("k_front", k_front<1>, grid, dim3(kThreads), s, in, out, n, plan_dev, meter_dev, hopsums, hop_stride, peaks, pre_gain, seg, warm);

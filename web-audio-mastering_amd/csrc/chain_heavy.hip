@@ -346,7 +346,8 @@ int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_
     WAM_LAUNCH("k_warm", (k_warm_punch<true, false>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
   }
   if (do_punch) {
-    const int64_t warm = scale_warm(tuning().punch_warm_tiles, sr), seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
+    // 48 tiles of warm-up: one resident round of workgroups (4 per CU) rather than two
+    const int64_t warm = scale_warm(tuning().punch_warm_tiles, sr), seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles, 1024);
     WAM_LAUNCH("k_punch", (k_warm_punch<false, true>), dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, nch, n, plan_dev, env, pre_gain, seg, warm);
   }
   return WAM_OK;
