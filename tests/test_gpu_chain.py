@@ -185,3 +185,39 @@ def test_hot_material_margin():
                 assert d.max() <= 1e-6, (over, d.max())
             else:
                 assert d.max() <= 1e-4 and (d > 1e-5).mean() <= 1e-3, (over, d.max(), (d > 1e-5).mean())
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 255, 257, 2047, 2048, 2049, 2560, 4095, 4097, 4799, 4801, 19199, 19201])
+@pytest.mark.parametrize("nch", [1, 2])
+def test_ragged_fx_and_chain(n, nch):
+    """Tiny and ragged lengths (below one FFT frame, one tile, one LUFS hop / block, around each boundary), mono and stereo: every
+    heavy stage and the whole chain against the oracle."""
+    sr = 48000
+    x = O.synth(70 + n % 7, nch, n, sr, {"amp": 1.9, "clickAmp": 0.6})
+    assert maxerr(wam.apply_exciter(x, sr), O.exciter(x, sr)) <= PCM_TOL
+    assert maxerr(wam.apply_tape_warmth(x, sr), O.warmth(x, sr)) <= PCM_TOL
+    assert maxerr(wam.apply_multiband_transient(x, sr), O.punch(x, sr)) <= PCM_TOL
+    if HAVE_DEHARSH:
+        assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= PCM_TOL
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=HAVE_DEHARSH, glueCompression=True, eqLow=1, eqHigh=2, cutMud=True)
+    y, res = wam.render_full_chain(x, sr, s, "export")
+    yo, ro = O.render_chain(x, sr, s, "export")
+    assert maxerr(y, yo) <= PCM_TOL
+    close(res.lufs, ro.lufs, LUFS_TOL)
+    close(res.true_peak_db, ro.true_peak_db, TP_TOL)
+
+
+def test_empty_input_everywhere():
+    """n = 0: every entry point returns empty outputs (or the documented sentinel) without touching the device's data path."""
+    sr = 48000
+    z = [np.zeros(0, np.float32)] * 2
+    for fn in (wam.apply_exciter, wam.apply_tape_warmth, wam.apply_multiband_transient, wam.apply_final_filters, wam.apply_glue_compressor,
+               wam.apply_mastering_soft_clip):
+        out = fn(z, sr)
+        assert len(out) == 2 and len(out[0]) == 0
+    if HAVE_DEHARSH:
+        assert len(wam.process_hybrid_dynamic(z, sr)[0]) == 0
+    y, res = wam.render_full_chain(z, sr, dict(wam.DEFAULT_SETTINGS), "export")
+    assert len(y[0]) == 0
+    assert wam.measure_lufs(z, sr) == -14.0 and wam.find_true_peak(z) == float("-inf")
+    assert len(wam.encode_pcm24(z)) == 0
