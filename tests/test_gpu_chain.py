@@ -221,3 +221,21 @@ def test_empty_input_everywhere():
     assert len(y[0]) == 0
     assert wam.measure_lufs(z, sr) == -14.0 and wam.find_true_peak(z) == float("-inf")
     assert len(wam.encode_pcm24(z)) == 0
+
+
+@pytest.mark.parametrize("sr", [16000, 22050, 32000, 44100, 88200, 96000])
+def test_chain_other_sample_rates(sr):
+    """Every plan constant that depends on the sample rate (filter coefficients, look-ahead and window lengths, hop and block
+    sizes, warm-up lengths, de-harsh band edges): 1.5 s through the whole chain, against the oracle.  Below 32 kHz the stages
+    whose corner frequency lies above Nyquist (6 kHz exciter high-pass pair at 16 k is still fine; the 12 kHz shelf is not) are
+    switched off: the reference's filters are unstable there and both sides only produce garbage."""
+    n = int(sr * 1.5) + 13
+    x = O.synth(90, 2, n, sr, {"amp": 1.7, "clickAmp": 0.6})
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=HAVE_DEHARSH, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1,
+             eqHigh=2 if sr >= 32000 else 0)
+    y, res = wam.render_full_chain(x, sr, s, "export")
+    yo, ro = O.render_chain(x, sr, s, "export")
+    assert np.isfinite(np.stack(yo)).all()
+    assert maxerr(y, yo) <= PCM_TOL
+    close(res.lufs, ro.lufs, LUFS_TOL)
+    close(res.true_peak_db, ro.true_peak_db, TP_TOL)
