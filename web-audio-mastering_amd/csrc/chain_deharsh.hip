@@ -6,11 +6,12 @@
 // 2048-point STFT, hop 512, per channel:
 //   k_dh_bands : every frame in parallel -> windowed FFT -> 7 band RMS values          (parallel over frames)
 //   k_dh_follow: per (channel, band) the per-frame envelope follower + soft-knee gain  (serial over frames, tiny)
-//   k_dh_apply : one workgroup per channel walks the frames in order: FFT, per-bin resonance EMA (state per
-//                bin in registers), gains, inverse FFT, synthesis window, overlap-add in LDS, 85/15 dry/wet mix.
-// The FFT runs in float32 in LDS (radix-2 stages fused in pairs, DIF forward / DIT inverse, no bit-reversal
-// pass); the reference's FFT is double (npm fft.js, absent: parity unpinned at that boundary).  The wet path
-// is scaled by 0.15 * 0.375, so float32 FFT rounding (~1e-6 relative) is ~1e-7 of full scale in the output.
+//   k_dh_apply : one wavefront per (channel, segment of frames) walks its frames in order: FFT, per-bin resonance EMA and
+//                overlap-add ring in registers, gains, inverse FFT, synthesis window, 85/15 dry/wet mix.
+// The FFT runs in float32, one wavefront per frame, sixteen points per lane (see "the transform" below); the reference's FFT
+// is double (npm fft.js, absent: parity unpinned at that boundary).  The wet path is scaled by 0.15 * 0.375, so float32 FFT
+// rounding (~1e-6 relative) is ~1e-7 of full scale in the stage's output (DESIGN.md 2 for what the soft clipper makes of it
+// on hard-driven masters).
 #include "chain.hpp"
 #include <cmath>
 #include <cstring>
@@ -36,7 +37,7 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2
 //
 // One WAVEFRONT transforms one frame: 1024 = 16 x 16 x 4, sixteen points per lane.
 //   1. lane l holds z[64 r + l], r = 0..15: a 16-point DFT over r in registers            -> A[k1], k1 = 0..15
-//   2. twiddle A[k1] *= W1024^(l k1)   (per-lane constants, kept in registers for the whole kernel)
+//   2. twiddle A[k1] *= W1024^(l k1)   (per-lane constants, read from an LDS table with unit stride across lanes)
 //   3. one exchange through LDS (rows of k1, 64 + 4 columns): lane (k1' = lane >> 2, q = lane & 3) takes
 //      A'[k1'][q + 4 m], m = 0..15
 //   4. a second 16-point DFT over m in registers                                            -> B[j1]
@@ -44,8 +45,7 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2
 //   6. a radix-4 butterfly across the four lanes of a quad (DPP quad_perm moves, no LDS): lane (k1', q) ends up with
 //      Z[k1' + 16 j1 + 256 rev2(q)], j1 = 0..15.
 // That is 2 LDS round trips per transform instead of the 5 of a radix-4 pass structure over 256 threads, and the only
-// synchronisation inside a transform is the one between the exchange's writes and reads.  The four wavefronts of a
-// workgroup transform four consecutive frames at the same time.
+// synchronisation inside a transform is the wavefront-local one between the exchange's writes and reads.
 constexpr int kM = 1024, kTw1 = 1024, kTwB = 513;    // tables: W1024^k, k < 1024; W2048^k, k <= 512
 constexpr int kExRow = 68;                           // exchange row stride (float2): 16 rows land on distinct banks
 constexpr int kWaveBuf = 16 * kExRow;                // float2 per wavefront buffer (>= 1024)
@@ -120,7 +120,7 @@ __device__ __forceinline__ void load_wave_tw(const float2* __restrict__ tw1, Wav
 __device__ __forceinline__ int wave_out_base() { const int lane = lane_id(), q = lane & 3; return (lane >> 2) + 256 * (((q & 1) << 1) | (q >> 1)); }
 
 // v[r] = z[64 r + lane] on entry; on return v[j1] = Z[wave_out_base() + 16 j1].  `ex` = this wavefront's LDS buffer
-// (kWaveBuf float2); contains a workgroup barrier (all four wavefronts transform in step).  Unnormalised both ways.
+// (kWaveBuf float2), touched by no other wavefront.  Unnormalised both ways.
 // Orders this wavefront's LDS writes before its later LDS reads (other lanes' data) without a workgroup barrier: the
 // LDS unit executes one wavefront's instructions in order, so only the compiler has to be kept from reordering.
 __device__ __forceinline__ void wave_sync() {
