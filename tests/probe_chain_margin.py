@@ -1,4 +1,4 @@
-"""Prints the PCM error of the GPU chain against the CPU oracle for the settings of tests/test_gpu_chain.py (margin to 1e-5)."""
+"""(Test infrastructure, run by hand: python tests/probe_chain_margin.py on a GPU box.)  Prints the PCM error of the GPU chain against the CPU oracle for the settings of tests/test_gpu_chain.py (margin to 1e-5)."""
 import sys, os
 sys.path.insert(0, "web-audio-mastering_amd/python"); sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch, wam

@@ -1,4 +1,4 @@
-"""Worst-case probe: long hot tracks through the full chain with de-harsh on, GPU vs CPU oracle (the soft clipper amplifies upstream differences)."""
+"""(Test infrastructure, run by hand: python tests/probe_hot_margin.py on a GPU box.)  Worst-case probe: long hot tracks through the full chain with de-harsh on, GPU vs CPU oracle (the soft clipper amplifies upstream differences)."""
 import sys, time
 sys.path.insert(0, "web-audio-mastering_amd/python"); sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch, wam

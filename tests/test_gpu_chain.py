@@ -172,7 +172,7 @@ def test_hot_material_margin():
     """The soft clipper multiplies upstream differences by up to ~550 near its threshold.  Without de-harsh every
     stage ahead of it is faithful to the f32 stores and the chain stays within 1e-6 of the oracle even when driven hard; with
     de-harsh (float32 FFT, ~1e-7 on its own output) a small fraction of the samples of a hard-driven master exceeds the 1e-5
-    bar - measured and bounded here so that it cannot grow unnoticed (tools/hot_margin.py probes 30 s tracks)."""
+    bar - measured and bounded here so that it cannot grow unnoticed (tests/probe_hot_margin.py probes 30 s tracks)."""
     sr, n = 48000, 48000 * 10
     x = O.synth(60, 2, n, sr, {"amp": 1.8, "clickAmp": 0.7})
     for over in (dict(targetLufs=-9, truePeakCeiling=-0.3, inputGain=6), dict(targetLufs=-7, inputGain=3, glueCompression=True)):
