@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ i
   const float* x = in + chan * n;
   float* y = out + chan * n;
   const int lane = lane_id(), wave = wave_id();
-  const float dry = 1 - 0.15, wetm = 0.15;                          // preset dryWetMix 0.15, dynamic-processor.js:419-423
+  const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423 (doubles: 0.85f is not 0.85)
   const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
   WaveTw T; load_wave_tw(twg, T, tws);
   for (int i = threadIdx.x; i < kM / 2; i += 256) twBs[i] = twg[kTw1 + i];
