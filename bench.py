@@ -146,6 +146,7 @@ def main():
                     help="chain: configs[2] (default, the bench line); meter: configs[0] batched; single: configs[1], one 3-min track; "
                          "longform: configs[3], one 60-min 96 kHz track; stft: configs[4], 4096-point STFT hop 1024 over the corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wam_tune knob for an experiment (e.g. dh_exact=1); recorded in config")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +169,8 @@ def main():
     dev = torch.device("cuda", local_rank if (world > 1 and not rehearsal) else 0)
     comm = torch.device("cpu") if rehearsal else dev            # where the collectives' tensors live
     wam.init(dev.index)
+    for kv in args.tune:
+        wam.tune(kv.split("=")[0], int(kv.split("=")[1]))
 
     global SR, SECONDS, N
     wl = args.workload
@@ -267,7 +270,8 @@ def main():
                                     if wl == "stft" else
                                     f"BASELINE configs[0] batched: {T} tracks/GPU x 3-min stereo 48 kHz, integrated LUFS + true peak"),
                        "tracks_per_gpu": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
-                       "settings": C2_SETTINGS if chain_like else None, "parallelism": f"track-sharded x{world}, no collective"},
+                       "settings": C2_SETTINGS if chain_like else None, "parallelism": f"track-sharded x{world}, no collective",
+                       **({"tune": args.tune} if args.tune else {})},
             "roofline": roofline,
             "chain_hbm_frac": (chain_bytes / (kernel_ms_per_step * 1e-3) / 8e12) if kernel_ms_per_step > 0 else None,
             "kernel_ms_per_step": kernel_ms_per_step,

@@ -169,22 +169,29 @@ def test_host_batch_equals_single():
 
 
 def test_hot_material_margin():
-    """The soft clipper multiplies upstream differences by up to ~550 near its threshold.  Without de-harsh every
-    stage ahead of it is faithful to the f32 stores and the chain stays within 1e-6 of the oracle even when driven hard; with
-    de-harsh (float32 FFT, ~1e-7 on its own output) a small fraction of the samples of a hard-driven master exceeds the 1e-5
-    bar - measured and bounded here so that it cannot grow unnoticed (tests/probe_hot_margin.py probes 30 s tracks)."""
+    """The soft clipper multiplies upstream differences by up to ~550 near its threshold, so a hard-driven master
+    is the severest parity case there is.  Every stage ahead of the clipper is faithful to the reference's f32 stores - the
+    de-harsh stage included, with its default kernels - and the chain stays within 1e-6 of the oracle.  With the float32
+    de-harsh kernels (wam_tune("dh_exact", 0): ~1e-7 on their own output) a small fraction of the samples of such a master
+    exceeds the 1e-5 bar; measured and bounded here so that it cannot grow unnoticed (tests/probe_hot_margin.py: 30 s tracks)."""
     sr, n = 48000, 48000 * 10
     x = O.synth(60, 2, n, sr, {"amp": 1.8, "clickAmp": 0.7})
-    for over in (dict(targetLufs=-9, truePeakCeiling=-0.3, inputGain=6), dict(targetLufs=-7, inputGain=3, glueCompression=True)):
-        for dh in (False, True):
-            s = dict(wam.DEFAULT_SETTINGS, deharsh=dh, **over)
-            y, _ = wam.render_full_chain(x, sr, s, "export")
-            yo, _ = O.render_chain(x, sr, s, "export")
-            d = np.concatenate([np.abs(a.astype(np.float64) - b) for a, b in zip(y, yo)])
-            if not dh:
-                assert d.max() <= 1e-6, (over, d.max())
-            else:
-                assert d.max() <= 1e-4 and (d > 1e-5).mean() <= 1e-3, (over, d.max(), (d > 1e-5).mean())
+    try:
+        for over in (dict(targetLufs=-9, truePeakCeiling=-0.3, inputGain=6), dict(targetLufs=-7, inputGain=3, glueCompression=True)):
+            for dh, exact in ((False, 1), (True, 1), (True, 0)):
+                if dh and not HAVE_DEHARSH:
+                    continue
+                wam.tune("dh_exact", exact)
+                s = dict(wam.DEFAULT_SETTINGS, deharsh=dh, **over)
+                y, _ = wam.render_full_chain(x, sr, s, "export")
+                yo, _ = O.render_chain(x, sr, s, "export")
+                d = np.concatenate([np.abs(a.astype(np.float64) - b) for a, b in zip(y, yo)])
+                if exact:
+                    assert d.max() <= 1e-6, (over, dh, d.max())
+                else:
+                    assert d.max() <= 1e-4 and (d > 1e-5).mean() <= 1e-3, (over, d.max(), (d > 1e-5).mean())
+    finally:
+        wam.tune("reset")
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 255, 257, 2047, 2048, 2049, 2560, 4095, 4097, 4799, 4801, 19199, 19201])
@@ -243,8 +250,7 @@ def test_chain_other_sample_rates(sr):
 
 def test_chain_random_settings():
     """Forty random points of the settings space (every switch, every slider over its UI range, controls.js:66-135), seeded: the
-    chain against the oracle.  With de-harsh on, a hard-driven draw may exceed 1e-5 on a few samples (test_hot_material_margin);
-    without it the bar is the plain one."""
+    chain against the oracle, to the plain 1e-5 bar whatever the draw (hard-driven ones with de-harsh included)."""
     rng = np.random.default_rng(2024)
     sr, n = 48000, 40000
     x = O.synth(95, 2, n, sr, {"amp": 1.6, "clickAmp": 0.6, "dc": 0.0005})
@@ -260,9 +266,6 @@ def test_chain_random_settings():
         y, res = wam.render_full_chain(x, sr, s, mode)
         yo, ro = O.render_chain(x, sr, s, mode)
         d = np.concatenate([np.abs(a.astype(np.float64) - c) for a, c in zip(y, yo)])
-        if s["deharsh"]:
-            assert d.max() <= 1e-4 and (d > 1e-5).mean() <= 1e-3, (k, s, d.max())
-        else:
-            assert d.max() <= PCM_TOL, (k, s, d.max())
+        assert d.max() <= PCM_TOL, (k, s, d.max())
         close(res.lufs, ro.lufs, LUFS_TOL)
         close(res.true_peak_db, ro.true_peak_db, TP_TOL)

@@ -33,9 +33,11 @@ def hot():
     return sr, O.synth(11, 2, 3 * sr + 777, sr, {"amp": 2.4, "clickAmp": 0.8, "dc": 0.002})
 
 
-def test_deharsh_segments(hot):
+@pytest.mark.parametrize("exact", [1, 0])
+def test_deharsh_segments(hot, exact):
     sr, x = hot
     ref = O.deharsh(x, sr)
+    wam.tune("dh_exact", exact)                # exact kernels: the warm-up is raised to 128 frames whatever the knob says
     wam.tune("dh_seg_frames", 1 << 20)
     whole = wam.process_hybrid_dynamic(x, sr)
     assert maxerr(whole, ref) <= TOL

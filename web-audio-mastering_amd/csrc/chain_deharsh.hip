@@ -25,6 +25,7 @@ struct DeharshPlan {
   double thr[kBands], ks[kBands], ke[kBands], knee[kBands], ratio[kBands], A[kBands], R[kBands];
   float cnt[kBands];
   int64_t nframes;
+  int band_start[kBands + 1];    // band b = bins [band_start[b], band_start[b + 1]) (the bands are ascending frequency ranges)
   uint8_t band_of[kBins];
 };
 
@@ -486,6 +487,328 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ i
   }
 }
 
+
+// =====================================================================================================================
+// Exact mode (wam_tune("dh_exact", 1)).  The kernels above keep the stage within ~1e-7 of the reference, which is one f32 ulp on
+// ~9 % of its output samples; the mastering soft clipper downstream multiplies a one-ulp difference by up to ~550 on
+// hard-driven material.  The kernels below reproduce every Float32Array store of the reference instead: the
+// transform in double (same wavefront-per-frame structure), magnitudes rounded to f32 from the double spectrum, the band
+// energies as the reference's SEQUENTIAL f32 sums in bin order (dynamic-processor.js:327-332: one lane per band walks its
+// bins), resonance / gain arithmetic in double with f32 stores where the reference has Float32Arrays.  Slower (one
+// workgroup per CU, a 512-step dependent chain per frame); the default stays the float32 path.
+struct dcx { double x, y; };
+__device__ __forceinline__ dcx dmul(dcx a, dcx b) { return dcx{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
+__device__ __forceinline__ dcx dmulc(dcx a, dcx b) { return dcx{ a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y }; }
+
+template <bool INV>
+__device__ __forceinline__ void r4_butterfly_d(dcx a[4]) {
+  const dcx s02{ a[0].x + a[2].x, a[0].y + a[2].y }, d02{ a[0].x - a[2].x, a[0].y - a[2].y };
+  const dcx s13{ a[1].x + a[3].x, a[1].y + a[3].y }, d13{ a[1].x - a[3].x, a[1].y - a[3].y };
+  a[0] = dcx{ s02.x + s13.x, s02.y + s13.y };
+  a[2] = dcx{ s02.x - s13.x, s02.y - s13.y };
+  if (!INV) { a[1] = dcx{ d02.x + d13.y, d02.y - d13.x }; a[3] = dcx{ d02.x - d13.y, d02.y + d13.x }; }
+  else { a[1] = dcx{ d02.x - d13.y, d02.y + d13.x }; a[3] = dcx{ d02.x + d13.y, d02.y - d13.x }; }
+}
+template <bool INV, int P>
+__device__ __forceinline__ dcx mul_w16_d(dcx a) {
+  constexpr double h = 0.70710678118654752440, c = 0.92387953251128675613, s = 0.38268343236508977173;
+  if (P == 0) return a;
+  if (P == 4) return INV ? dcx{ -a.y, a.x } : dcx{ a.y, -a.x };
+  if (P == 2) return INV ? dcx{ h * (a.x - a.y), h * (a.x + a.y) } : dcx{ h * (a.x + a.y), h * (a.y - a.x) };
+  if (P == 6) return INV ? dcx{ -h * (a.x + a.y), h * (a.x - a.y) } : dcx{ h * (a.y - a.x), -h * (a.x + a.y) };
+  const double wr = P == 1 ? c : (P == 3 ? s : -c), wi = P == 1 ? -s : (P == 3 ? -c : s);
+  return INV ? dmulc(a, dcx{ wr, wi }) : dmul(a, dcx{ wr, wi });
+}
+template <bool INV>
+__device__ __forceinline__ void dft16_d(dcx v[16]) {
+  dcx T[4][4];
+#pragma unroll
+  for (int r0 = 0; r0 < 4; r0++) {
+    dcx a[4] = { v[r0], v[r0 + 4], v[r0 + 8], v[r0 + 12] };
+    r4_butterfly_d<INV>(a);
+#pragma unroll
+    for (int ka = 0; ka < 4; ka++) T[r0][ka] = a[ka];
+  }
+  T[1][1] = mul_w16_d<INV, 1>(T[1][1]); T[1][2] = mul_w16_d<INV, 2>(T[1][2]); T[1][3] = mul_w16_d<INV, 3>(T[1][3]);
+  T[2][1] = mul_w16_d<INV, 2>(T[2][1]); T[2][2] = mul_w16_d<INV, 4>(T[2][2]); T[2][3] = mul_w16_d<INV, 6>(T[2][3]);
+  T[3][1] = mul_w16_d<INV, 3>(T[3][1]); T[3][2] = mul_w16_d<INV, 6>(T[3][2]); T[3][3] = mul_w16_d<INV, 9>(T[3][3]);
+#pragma unroll
+  for (int ka = 0; ka < 4; ka++) {
+    dcx b[4] = { T[0][ka], T[1][ka], T[2][ka], T[3][ka] };
+    r4_butterfly_d<INV>(b);
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) v[ka + 4 * kb] = b[kb];
+  }
+}
+__device__ __forceinline__ double quad_xor2_d(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_xor1_d(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// tables in global memory (double): twl[64 (k - 1) + lane] = W1024^(lane k), twq[16 q + k] = W64^(q k), twB[k] = W2048^k
+struct WaveTwD { const dcx* l; const dcx* q; };
+template <bool INV>
+__device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD& T) {
+  const int lane = lane_id(), q = lane & 3;
+  dft16_d<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; k++) { const dcx w = T.l[64 * (k - 1) + lane]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) ex[k * kExRow + lane] = v[k];
+  wave_sync();
+  const dcx* row = ex + (lane >> 2) * kExRow + q;
+#pragma unroll
+  for (int m = 0; m < 16; m++) v[m] = row[4 * m];
+  dft16_d<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; k++) { const dcx w = T.q[16 * q + k]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
+  const double sg1 = (q & 2) ? -1.0 : 1.0, sg2 = (q & 1) ? -1.0 : 1.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    dcx a{ fma(sg1, v[k].x, quad_xor2_d(v[k].x)), fma(sg1, v[k].y, quad_xor2_d(v[k].y)) };
+    if (q == 3) a = INV ? dcx{ -a.y, a.x } : dcx{ a.y, -a.x };
+    v[k] = dcx{ fma(sg2, a.x, quad_xor1_d(a.x)), fma(sg2, a.y, quad_xor1_d(a.y)) };
+  }
+}
+struct BinPairD { dcx xe, t; };
+__device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
+  const dcx bq{ zm.x, -zm.y };
+  BinPairD p;
+  p.xe = dcx{ 0.5 * (zk.x + bq.x), 0.5 * (zk.y + bq.y) };
+  const dcx d{ 0.5 * (zk.x - bq.x), 0.5 * (zk.y - bq.y) };
+  p.t = dmul(dcx{ d.y, -d.x }, w);
+  return p;
+}
+__device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, dcx v[16]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = 2 * (64 * r + lane);
+    float v0 = x[pos + i], v1 = x[pos + i + 1];
+    if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
+    if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
+    if (!(v1 == v1)) v1 = 0.0f;
+    v[r] = dcx{ (double)f32r((double)v0 * (double)win[i]), (double)f32r((double)v1 * (double)win[i + 1]) };   // inputBuffer is a Float32Array (fft.js:30,44)
+  }
+}
+// magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
+__device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X.y * X.y)); }
+
+__global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
+                                                       const dcx* __restrict__ twd, const float* __restrict__ wing,
+                                                       float* __restrict__ band_rms, double pre_gain) {
+  __shared__ dcx buf[4][kWaveBuf];
+  const DeharshPlan& P = *dp;
+  const int64_t chan = blockIdx.y;
+  const float* x = in + chan * n;
+  const int lane = lane_id(), wave = wave_id();
+  dcx* z = buf[wave];
+  const int ob = wave_out_base();
+  const int64_t ngroups = (P.nframes + 3) / 4;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t f = 4 * g + wave;
+    if (f >= P.nframes) break;
+    dcx v[16];
+    const dcx* twf = reload_each_tile(twd);                       // tables re-read per frame, not hoisted into ~200 registers
+    const WaveTwD T{ twf, twf + kTwl };
+    const dcx* twB = twf + kTwl + kTwq;
+    load_frame_d(x, f * kHop, reload_each_tile(wing), pre_gain, v);
+    wave_sync();
+    fft1024_wave_d<false>(v, z, T);
+#pragma unroll
+    for (int j = 0; j < 16; j++) z[ob + 16 * j] = v[j];
+    wave_sync();
+    float mk[8], mm[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = lane + 64 * j;
+      if (k == 0) {
+        const dcx z0 = z[0], zh = z[512];
+        mk[j] = f32r(fabs(z0.x + z0.y)); mm[j] = mag_f32(zh);          // X[0] = Re + Im of Z[0] (real); bin 512 = conj Z[512]
+      } else {
+        const BinPairD p = split_pair_d(z[k], z[kM - k], twB[k]);
+        mk[j] = mag_f32(dcx{ p.xe.x + p.t.x, p.xe.y + p.t.y });
+        mm[j] = mag_f32(dcx{ p.xe.x - p.t.x, p.xe.y - p.t.y });
+      }
+    }
+    wave_sync();                                                   // everybody has read Z: the buffer becomes the magnitude array
+    float* mags = (float*)z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int k = lane + 64 * j; mags[k] = mk[j]; mags[k == 0 ? 512 : kM - k] = mm[j]; }
+    wave_sync();
+    if (lane < kBands) {                                           // bandEnergies[b] += mag * mag in bin order, a Float32Array (:327-339)
+      float be = 0.0f;
+      const int k1 = P.band_start[lane + 1];
+      int k = P.band_start[lane];
+      for (; k + 8 <= k1; k += 8) {                                // loads up front: the adds are the dependent chain
+        float m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) m8[u] = mags[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const double m = m8[u]; be = f32r((double)be + m * m); }
+      }
+      for (; k < k1; k++) { const double m = mags[k]; be = f32r((double)be + m * m); }
+      const float rms = P.cnt[lane] > 0 ? f32r(sqrt((double)be / (double)P.cnt[lane])) : be;
+      band_rms[(chan * P.nframes + f) * kBands + lane] = rms;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                       const DeharshPlan* __restrict__ dp, const dcx* __restrict__ twd,
+                                                       const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
+                                                       int64_t seg_frames, int64_t nseg, int64_t warm) {
+  __shared__ dcx buf[4][kWaveBuf];
+  __shared__ float bgs[4][8];
+  const DeharshPlan& P = *dp;
+  const int64_t chan = blockIdx.y;
+  const float* x = in + chan * n;
+  float* y = out + chan * n;
+  const int lane = lane_id(), wave = wave_id();
+  const double dry = 1 - 0.15, wetm = 0.15;
+  const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
+  if (seg >= nseg) return;
+  auto load_in = [&](int64_t s) -> float {
+    float v = (s < n) ? x[s] : 0.0f;
+    if (pre_gain != 1.0) v = f32r((double)v * pre_gain);
+    return v;
+  };
+  const int64_t F = P.nframes;
+  const int64_t f0 = seg * seg_frames;
+  int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
+  const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
+  const bool last_seg = f1 >= F;
+  const int ob = wave_out_base();
+  dcx* zw = buf[wave];
+  float* bg = bgs[wave];
+  uint64_t bands = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = lane + 64 * j;
+    bands |= (uint64_t)P.band_of[k] << (3 * j) | (uint64_t)P.band_of[k == 0 ? 512 : kM - k] << (24 + 3 * j);
+  }
+  float avg[16], acc[32];
+#pragma unroll
+  for (int j = 0; j < 16; j++) avg[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 32; j++) acc[j] = 0.0f;
+  for (int64_t f = fs; f < f1; f++) {
+    const bool synth = f + 3 >= f0;
+    const bool first = f == fs;
+    dcx v[16];
+    // the tables are re-read every frame through opaque pointers: hoisted out of the frame loop (they are loop-invariant
+    // global loads) they would occupy ~200 registers and force one wavefront per SIMD
+    const float* win = reload_each_tile(wing);
+    const dcx* twf = reload_each_tile(twd);
+    WaveTwD T{ twf, twf + kTwl };
+    const dcx* twB = twf + kTwl + kTwq;
+    load_frame_d(x, f * kHop, win, pre_gain, v);
+    if (lane < kBands) bg[lane] = band_gdb[(chan * F + f) * kBands + lane];
+    wave_sync();
+    fft1024_wave_d<false>(v, zw, T);
+#pragma unroll
+    for (int j = 0; j < 16; j++) zw[ob + 16 * j] = v[j];
+    wave_sync();
+    // ResonanceDetector.analyze (:194-233) and the gain of one bin (:361-382), with the reference's Float32Array stores
+    auto bin_gain = [&](float mag, float& av_state, int band) -> double {
+      float res = 0.0f;
+      if (first) av_state = mag;
+      else {
+        av_state = f32r(0.3 * (double)mag + (1 - 0.3) * (double)av_state);
+        const double av = av_state;
+        if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, (div_fast((double)mag, av) - 1.5) / 2));
+      }
+      double gdb = bg[band];
+      if (res > 0) gdb += -3.0 * (double)res * 0.2;
+      return (double)f32r(exp_fast(gdb / 20 * 2.30258509299404568402));   // 10^(gdb / 20); gains is a Float32Array (:320,:381)
+    };
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+      const int k = lane + 64 * j;
+      const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;
+      if (k == 0) {
+        const dcx z0 = zw[0], zh = zw[512];
+        const double x0 = z0.x + z0.y, xny = z0.x - z0.y;         // X[0] and X[1024] are real; the Nyquist bin is not scaled
+        const double g0 = bin_gain(f32r(fabs(x0)), avg[0], bk);
+        const double gh = bin_gain(mag_f32(zh), avg[1], bm);
+        if (synth) {
+          const double y0 = x0 * g0;
+          zw[0] = dcx{ 0.5 * (y0 + xny), 0.5 * (y0 - xny) };
+          zw[512] = dcx{ zh.x * gh, zh.y * gh };
+        }
+      } else {
+        const dcx zk = zw[k], zm = zw[kM - k];
+        const dcx wtw = twB[k];
+        const BinPairD p = split_pair_d(zk, zm, wtw);
+        const dcx xk{ p.xe.x + p.t.x, p.xe.y + p.t.y }, xmc{ p.xe.x - p.t.x, p.xe.y - p.t.y };
+        // (avg[] is indexed dynamically here: the loop is rolled to keep the double-precision code small)
+        float a0 = avg[0], a1 = avg[1];
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == j) { a0 = avg[2 * q]; a1 = avg[2 * q + 1]; }
+        const double gk = bin_gain(mag_f32(xk), a0, bk);
+        const double gm = bin_gain(mag_f32(xmc), a1, bm);
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == j) { avg[2 * q] = a0; avg[2 * q + 1] = a1; }
+        if (synth) {
+          const dcx yk{ xk.x * gk, xk.y * gk }, ymc{ xmc.x * gm, xmc.y * gm };
+          const dcx ye{ 0.5 * (yk.x + ymc.x), 0.5 * (yk.y + ymc.y) };
+          const dcx yo = dmulc(dcx{ 0.5 * (yk.x - ymc.x), 0.5 * (yk.y - ymc.y) }, wtw);
+          zw[k] = dcx{ ye.x - yo.y, ye.y + yo.x };
+          zw[kM - k] = dcx{ ye.x + yo.y, yo.x - ye.y };
+        }
+      }
+    }
+    if (!synth) continue;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
+    twf = reload_each_tile(twf);
+    T = WaveTwD{ twf, twf + kTwl };
+    fft1024_wave_d<true>(v, zw, T);
+    win = reload_each_tile(win);
+    wave_sync();                                                   // the exchange's reads precede the float writes below (other layout)
+    float2* yf = (float2*)zw;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int m = ob + 16 * j;
+      // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
+      yf[m] = make_float2(f32r((v[j].x * (1.0 / kM)) * (double)win[2 * m]), f32r((v[j].y * (1.0 / kM)) * (double)win[2 * m + 1]));
+    }
+    wave_sync();
+    const float* yw = (const float*)zw;
+    const int64_t pos = f * kHop;
+    const int rot = (int)(pos & (kN - 1)), jdone = (int)(f & 3);
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      const int i = (lane + 64 * j - rot) & (kN - 1);
+      acc[j] += yw[i];
+      if ((j >> 3) == jdone) {
+        if (f >= f0) {
+          const int64_t s = pos + i;
+          y[s] = f32r((double)load_in(s) * dry + (double)f32r((double)acc[j] / 4.0) * wetm);
+        }
+        acc[j] = 0.0f;
+      }
+    }
+  }
+  if (!last_seg) return;
+  wave_sync();
+  float* ring = (float*)zw;
+#pragma unroll
+  for (int j = 0; j < 32; j++) ring[lane + 64 * j] = acc[j];
+  wave_sync();
+  const int64_t done = F > 0 ? F * kHop : 0;
+  const int64_t ring_end = F > 0 ? (F - 1) * kHop + kN : 0;
+  for (int64_t s = done + lane; s < n; s += 64) {
+    float w = 0.0f;
+    if (s < ring_end) w = f32r((double)ring[(int)(s & (kN - 1))] / 4.0);
+    y[s] = f32r((double)load_in(s) * dry + (double)w * wetm);
+  }
+}
+
 // ---------------------------------------------------------------------------- host
 static void make_deharsh_plan(double sr, int64_t n, DeharshPlan* p) {
   std::memset(p, 0, sizeof(*p));
@@ -503,6 +826,9 @@ static void make_deharsh_plan(double sr, int64_t n, DeharshPlan* p) {
     for (int b = 0; b < kBands; b++) if (fr >= lo[b] && fr < hi[b]) { bi = b; break; }
     p->band_of[k] = (uint8_t)bi; p->cnt[bi] += 1;
   }
+  for (int b = 0; b <= kBands; b++) p->band_start[b] = kBins;
+  for (int k = kBins - 1; k >= 0; k--) p->band_start[p->band_of[k]] = k;        // first bin of every band that has bins
+  for (int b = kBands - 1; b >= 0; b--) if (p->band_start[b] > p->band_start[b + 1]) p->band_start[b] = p->band_start[b + 1];   // empty bands
   p->nframes = n >= kN ? (int64_t)std::floor((double)(n - kN) / kHop) : 0;    // :445
 }
 
@@ -527,20 +853,37 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
+  const bool exact = tuning().dh_exact != 0;
+  DevBuf twd;
+  if (exact) {                                     // double tables: twl[15][64] lane-major, twq[4][16], twB[513]
+    std::vector<dcx> td(kTwl + kTwq + kTwB);
+    auto W = [](double num, double den) { const double a = -2 * M_PI * num / den; return dcx{ std::cos(a), std::sin(a) }; };
+    for (int i = 0; i < kTwl; i++) td[i] = W((double)((i & 63) * ((i >> 6) + 1)), kM);
+    for (int i = 0; i < kTwq; i++) td[kTwl + i] = W((double)(16 * (i >> 4) * (i & 15)), kM);
+    for (int k = 0; k < kTwB; k++) td[kTwl + kTwq + k] = W((double)k, kN);
+    rc = twd.alloc(sizeof(dcx) * td.size()); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(twd.p, td.data(), sizeof(dcx) * td.size(), hipMemcpyHostToDevice, s));
+    WAM_HIP(hipStreamSynchronize(s));              // td is a host temporary
+  }
   if (dp.nframes > 0) {
     const int64_t ngroups = (dp.nframes + 3) / 4;
     int64_t gx = ngroups < 2048 ? ngroups : 2048;
-    WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
+    if (exact) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
+                          winb.as<float>(), rms.as<float>(), pre_gain);
+    else WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
                plan.as<DeharshPlan>(), nchan, gdb.as<float>());
   }
   // segments are walked by wavefronts, four to a workgroup: aim at ~16 k wavefronts (12 are resident per CU)
-  const int64_t warm = tuning().dh_warm_frames;
-  const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, 16384, 2048);
+  // exact mode: the resonance EMA must forget its start to below one f32 rounding (0.7^128 = 1.5e-20), not to ~1e-7
+  const int64_t warm = exact && tuning().dh_warm_frames < 128 ? 128 : tuning().dh_warm_frames;
+  const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, exact ? 8192 : 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
-  WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
-             winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
+  if (exact) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
+                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
+  else WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
+                  winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return
   return WAM_OK;
 }
