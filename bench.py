@@ -47,6 +47,8 @@ KERNEL_BYTES = {
     "k_gain_meter": 8,     # read x, write x*G
     "k_dh_bands": 4,       # read x (the 4x frame overlap is served by L2)
     "k_dh_apply": 8,       # read x, write y
+    "k_dh_bands_x": 4,     # the default (store-for-store) de-harsh kernels: same traffic as the float32 pair
+    "k_dh_apply_x": 8,
     "k_exciter": 8,
     "k_win_peak": 4,
     "k_warm": 8,
