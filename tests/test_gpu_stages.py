@@ -187,6 +187,30 @@ def test_limiter_lib_twin():
     assert maxerr(a, b) > 1e-4                 # the twins do differ where the soft-knee pass engages
 
 
+@pytest.mark.skipif(not has("wam_deharsh"), reason="not built")
+@pytest.mark.parametrize("sr", [16000, 44100, 48000, 96000])
+def test_deharsh_band_sums_scan_equals_serial_walk(sr):
+    """The default de-harsh kernels form the reference's sequential f32 band sums with wavefront scans plus a walk over the sum's
+    binade crossings, verified per frame, and fall back to the bin-by-bin walk otherwise (csrc/chain_deharsh.hip,
+    band_energies_scan).  Both must give the same bits: hot material, a stretch of digital silence (zero sums: fallback), a
+    stretch at -400 dB (f32-denormal energies: fallback) and one at -150 dB (tiny but normal), all within one input."""
+    n = sr * 5
+    x = [c.copy() for c in O.synth(61, 2, n, sr, {"amp": 1.7, "clickAmp": 0.7})]
+    for c in x:
+        c[sr:2 * sr] = 0.0
+        c[2 * sr:3 * sr] *= np.float32(1e-20)
+        c[3 * sr:4 * sr] *= np.float32(3e-8)
+    try:
+        wam.tune("dh_scan_sums", 0)
+        y0 = wam.process_hybrid_dynamic(x, sr)
+        wam.tune("dh_scan_sums", 1)
+        y1 = wam.process_hybrid_dynamic(x, sr)
+    finally:
+        wam.tune("reset")
+    assert all(np.array_equal(a, b) for a, b in zip(y0, y1))
+    assert maxerr(y1, O.deharsh(x, sr)) <= TOL
+
+
 @pytest.mark.parametrize("sr,n,nch", [(44100, 50001, 2), (96000, 70003, 2), (48000, 30000, 1), (48000, 2047, 2), (48000, 2048 + 512, 1)])
 def test_deharsh_rates_and_shapes(sr, n, nch, dh_mode):
     """De-harsh at other sample rates (band edges move), odd lengths (channel 1 is then not 8-byte aligned: the scalar load path),

@@ -597,16 +597,148 @@ __device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_
 // magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
 __device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X.y * X.y)); }
 
+// ---- the reference's sequential f32 band sums without the 512-step dependent chain -----------------------------------------
+// bandEnergies[b] += mag * mag on a Float32Array (dynamic-processor.js:327-332) is s <- RN24(RN53(s + a)) bin after bin.  While the
+// running sum stays inside one binade [2^E, 2^(E+1)) it is a multiple of u = 2^(E-23), so the step is s <- s + u rint(a / u):
+// an exact, order-free add of a quantised addend (unless a / u sits on a rounding tie, where s's parity and the double
+// rounding decide: those frames take the serial walk).  Only the steps on which the sum changes binade ("crossings", ~10 per
+// band: the sum grows from the first bin's energy to the band's) need the value of s itself.  So, with lane l holding bins
+// 16 l .. 16 l + 15:
+//   1. guess every step's binade from an unrounded single-precision prefix sum per band (segmented wavefront scan);
+//   2. quantise the addends of the non-crossing steps to their guessed u and prefix-sum them per run between crossings
+//      (second segmented scan, exact in double);
+//   3. compact the crossings (addend, run sum before it) into an LDS list; lanes 0..6 walk their band's list serially
+//      with the exact step s <- f32((s + run) + a) and leave s after every crossing in the list;
+//   4. every bin rebuilds its s = s(last crossing) + run and checks its binade against the guess: if all 1024 agree, the
+//      guessed trajectory IS the true one and, by induction over the bins, every s is the sequential value.  Otherwise
+//      (a sum within ~1e-6 of a power of two, a tie, silence, denormals: a few frames in a thousand) the wavefront falls
+//      back to the serial walk.
+constexpr int kCross = 640;                      // crossing list capacity per frame (typically ~60)
+
+// start masks: bit i = bin 16 lane + i starts a segment.  Inclusive segmented prefix sum of val[16] over the wavefront.
+template <class T>
+__device__ __forceinline__ void seg_scan16(T val[16], unsigned starts, int lane) {
+  T run = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { run = ((starts >> i) & 1) ? val[i] : run + val[i]; val[i] = run; }
+  T v = run;
+  int fl = starts != 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T pv = __shfl_up(v, d);
+    const int pf = __shfl_up(fl, d);
+    if (lane >= d) { if (!fl) v += pv; fl |= pf; }
+  }
+  T carry = __shfl_up(v, 1);
+  if (lane == 0) carry = 0;
+  const int first = starts ? __builtin_ctz(starts) : 16;
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (i < first) val[i] += carry;
+}
+
+struct BandLanePlan { unsigned bsm, bem; uint64_t bands16; };   // band starts / ends among the lane's 16 bins, 3-bit band ids
+__device__ __forceinline__ BandLanePlan make_band_lane_plan(const DeharshPlan& P, int lane) {
+  BandLanePlan L{ 0u, 0u, 0ull };
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int k = 16 * lane + i;
+    const int b = P.band_of[k];
+    L.bands16 |= (uint64_t)b << (3 * i);
+    if (k == 0 || P.band_of[k - 1] != b) L.bsm |= 1u << i;
+    if (k == kBins - 1 || P.band_of[k + 1] != b) L.bem |= 1u << i;
+  }
+  return L;
+}
+
+// Returns true if the fast path verified; then bandE[b] (LDS, double holding an f32 value) is the energy of every non-empty band.
+__device__ __forceinline__ bool band_energies_scan(const float* mags, double* la, double* lR, int* lstart, double* bandE,
+                                                   const BandLanePlan& L, int lane) {
+  float m[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const float4 t = ((const float4*)(mags + 16 * lane))[i]; m[4 * i] = t.x; m[4 * i + 1] = t.y; m[4 * i + 2] = t.z; m[4 * i + 3] = t.w; }
+  double a[16];
+  float D[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { a[i] = (double)m[i] * (double)m[i]; D[i] = m[i] * m[i]; }
+  seg_scan16(D, L.bsm, lane);
+  int e[16];
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { e[i] = (int)(__float_as_uint(D[i]) >> 23) & 0xff; bad |= e[i] < 24 || e[i] > 250; }
+  int eprev = __shfl_up(e[15], 1);
+  unsigned xm = L.bsm;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { if (e[i] != eprev) xm |= 1u << i; eprev = e[i]; }
+  double R[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const double t = ldexp(a[i], 150 - e[i]);                    // a / u, u = 2^(E - 23), E = e - 127
+    const double r = rint(t);
+    const bool cross = (xm >> i) & 1;
+    if (!cross && fabs(fabs(t - r) - 0.5) < 9.5367431640625e-07) bad = true;    // within 2^-20 of a tie (double rounding zone: 2^-29)
+    R[i] = cross ? 0.0 : ldexp(r, e[i] - 150);
+  }
+  asm volatile("" : "+v"(xm));                                    // per-bin conditions are re-derived per phase, not kept in SGPR pairs
+  seg_scan16(R, xm, lane);
+  asm volatile("" : "+v"(xm));
+  const int cnt = __builtin_popcount(xm);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int pv = __shfl_up(incl, d); if (lane >= d) incl += pv; }
+  const int base = incl - cnt;
+  const int total = __shfl(incl, 63);
+  if (total > kCross) return false;                               // uniform
+  if (lane < 8) lstart[lane] = total;
+  wave_sync();
+  double Rprev = __shfl_up(R[15], 1);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if ((xm >> i) & 1) {
+      const int idx = base + __builtin_popcount(xm & ((1u << i) - 1u));
+      la[idx] = a[i]; lR[idx] = Rprev;
+      if ((L.bsm >> i) & 1) lstart[(int)(L.bands16 >> (3 * i)) & 7] = idx;
+    }
+    Rprev = R[i];
+  }
+  wave_sync();
+  if (lane < kBands) {                                            // the crossings of band `lane`, in order
+    const int ls = lstart[lane];
+    int le = total;
+    for (int b = lane + 1; b < 8; b++) { const int t = lstart[b]; if (t < le) le = t; }
+    double sv = 0.0;
+    for (int j = ls; j < le; j++) {
+      const double aj = la[j], rj = lR[j];
+      sv = (j == ls) ? (double)f32r(aj) : (double)f32r((sv + rj) + aj);
+      lR[j] = sv;
+    }
+  }
+  wave_sync();
+  asm volatile("" : "+v"(xm));
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int idx = base + __builtin_popcount(xm & ((2u << i) - 1u)) - 1;     // the latest crossing at or before this bin
+    const double sk = lR[idx] + R[i];
+    const int ek = (int)(__float_as_uint((float)sk) >> 23) & 0xff;
+    bad |= ek != e[i];
+    if ((L.bem >> i) & 1) bandE[(int)(L.bands16 >> (3 * i)) & 7] = sk;
+  }
+  wave_sync();
+  return __ballot(bad) == 0;
+}
+
+
 __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
-                                                       float* __restrict__ band_rms, double pre_gain) {
+                                                       float* __restrict__ band_rms, double pre_gain, int scan_sums) {
   __shared__ dcx buf[4][kWaveBuf];
+  static_assert(sizeof(float) * kBins + sizeof(double) * (2 * kCross + 8) + sizeof(int) * 8 <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   const int lane = lane_id(), wave = wave_id();
   dcx* z = buf[wave];
   const int ob = wave_out_base();
+  const BandLanePlan L = make_band_lane_plan(P, lane);
   const int64_t ngroups = (P.nframes + 3) / 4;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t f = 4 * g + wave;
@@ -639,9 +771,17 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; j++) { const int k = lane + 64 * j; mags[k] = mk[j]; mags[k == 0 ? 512 : kM - k] = mm[j]; }
     wave_sync();
+    double* la = (double*)(mags + kBins);                          // the rest of the wavefront's buffer: crossing lists, band results
+    double* lR = la + kCross;
+    double* bandE = lR + kCross;
+    int* lstart = (int*)(bandE + 8);
+    BandLanePlan Lf = L;                                           // opaque per frame: the 48 per-bin conditions derived from the masks are
+    asm volatile("" : "+v"(Lf.bsm), "+v"(Lf.bem), "+v"(Lf.bands16));   // loop-invariant, and hoisted they live in ~100 SGPRs across the transform
+    const bool fast = scan_sums && band_energies_scan(mags, la, lR, lstart, bandE, Lf, lane);
     if (lane < kBands) {                                           // bandEnergies[b] += mag * mag in bin order, a Float32Array (:327-339)
       float be = 0.0f;
-      const int k1 = P.band_start[lane + 1];
+      const int k1 = fast ? 0 : P.band_start[lane + 1];              // the serial walk when the scan did not verify
+      if (fast && P.cnt[lane] > 0) be = (float)bandE[lane];
       int k = P.band_start[lane];
       for (; k + 8 <= k1; k += 8) {                                // loads up front: the adds are the dependent chain
         float m8[8];
@@ -868,8 +1008,10 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   if (dp.nframes > 0) {
     const int64_t ngroups = (dp.nframes + 3) / 4;
     int64_t gx = ngroups < 2048 ? ngroups : 2048;
-    if (exact) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
-                          winb.as<float>(), rms.as<float>(), pre_gain);
+    // the exact kernel's per-workgroup set-up (band plan of every lane) wants long-lived workgroups: ~8 k in all (512 are resident)
+    int64_t gxx = 8192 / nchan; if (gxx < 1) gxx = 1; if (gxx > ngroups) gxx = ngroups;
+    if (exact) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gxx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
+                          winb.as<float>(), rms.as<float>(), pre_gain, (int)(tuning().dh_scan_sums != 0));
     else WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
