@@ -582,17 +582,12 @@ __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
   p.t = dmul(dcx{ d.y, -d.x }, w);
   return p;
 }
+// the windowed frame is a Float32Array in the reference (fft.js:30,44): load_frame()'s f32 product is that store; widened here
 __device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, dcx v[16]) {
-  const int lane = lane_id();
+  float2 vf[16];
+  load_frame(x, pos, win, pre_gain, vf);
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int i = 2 * (64 * r + lane);
-    float v0 = x[pos + i], v1 = x[pos + i + 1];
-    if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
-    if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
-    if (!(v1 == v1)) v1 = 0.0f;
-    v[r] = dcx{ (double)f32r((double)v0 * (double)win[i]), (double)f32r((double)v1 * (double)win[i + 1]) };   // inputBuffer is a Float32Array (fft.js:30,44)
-  }
+  for (int r = 0; r < 16; r++) v[r] = dcx{ (double)vf[r].x, (double)vf[r].y };
 }
 // magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
 __device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X.y * X.y)); }
@@ -865,11 +860,11 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       if (res > 0) gdb += -3.0 * (double)res * 0.2;
       return (double)f32r(exp_fast(gdb / 20 * 2.30258509299404568402));   // 10^(gdb / 20); gains is a Float32Array (:320,:381)
     };
-#pragma unroll 1
+#pragma unroll 1                                                   // rolled: unrolled, the eight bodies' loads are hoisted and spill
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
       const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;
-      if (k == 0) {
+      if (j == 0 && k == 0) {
         const dcx z0 = zw[0], zh = zw[512];
         const double x0 = z0.x + z0.y, xny = z0.x - z0.y;         // X[0] and X[1024] are real; the Nyquist bin is not scaled
         const double g0 = bin_gain(f32r(fabs(x0)), avg[0], bk);
@@ -884,14 +879,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         const dcx wtw = twB[k];
         const BinPairD p = split_pair_d(zk, zm, wtw);
         const dcx xk{ p.xe.x + p.t.x, p.xe.y + p.t.y }, xmc{ p.xe.x - p.t.x, p.xe.y - p.t.y };
-        // (avg[] is indexed dynamically here: the loop is rolled to keep the double-precision code small)
-        float a0 = avg[0], a1 = avg[1];
-#pragma unroll
-        for (int q = 0; q < 8; q++) if (q == j) { a0 = avg[2 * q]; a1 = avg[2 * q + 1]; }
-        const double gk = bin_gain(mag_f32(xk), a0, bk);
-        const double gm = bin_gain(mag_f32(xmc), a1, bm);
-#pragma unroll
-        for (int q = 0; q < 8; q++) if (q == j) { avg[2 * q] = a0; avg[2 * q + 1] = a1; }
+        const double gk = bin_gain(mag_f32(xk), avg[2 * j], bk);
+        const double gm = bin_gain(mag_f32(xmc), avg[2 * j + 1], bm);
         if (synth) {
           const dcx yk{ xk.x * gk, xk.y * gk }, ymc{ xmc.x * gm, xmc.y * gm };
           const dcx ye{ 0.5 * (yk.x + ymc.x), 0.5 * (yk.y + ymc.y) };
@@ -915,7 +904,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     for (int j = 0; j < 16; j++) {
       const int m = ob + 16 * j;
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
-      yf[m] = make_float2(f32r((v[j].x * (1.0 / kM)) * (double)win[2 * m]), f32r((v[j].y * (1.0 / kM)) * (double)win[2 * m + 1]));
+      const float2 ws = ((const float2*)(win + kN))[m];            // window / 1024 (exact scaling): the inverse's 1 / N folded in
+      yf[m] = make_float2(f32r(v[j].x * (double)ws.x), f32r(v[j].y * (double)ws.y));
     }
     wave_sync();
     const float* yw = (const float*)zw;
@@ -982,14 +972,15 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   int rc;
   rc = plan.alloc(sizeof(dp)); if (rc) return rc;
   rc = twb.alloc(sizeof(float2) * (kTw1 + kTwB)); if (rc) return rc;
-  rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
+  rc = winb.alloc(sizeof(float) * 2 * kN); if (rc) return rc;    // window, then window / 1024 (exact kernels' synthesis)
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   std::vector<float2> tw(kTw1 + kTwB);
-  std::vector<float> win(kN);
+  std::vector<float> win(2 * kN);
   for (int k = 0; k < kTw1; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int k = 0; k < kTwB; k++) { const double a = -2 * M_PI * k / kN; tw[kTw1 + k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int i = 0; i < kN; i++) win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / (kN - 1))));     // utils.js:98-104
+  for (int i = 0; i < kN; i++) win[kN + i] = win[i] * (1.0f / kM);
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
