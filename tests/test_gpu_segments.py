@@ -37,7 +37,7 @@ def hot():
 def test_deharsh_segments(hot, exact):
     sr, x = hot
     ref = O.deharsh(x, sr)
-    wam.tune("dh_exact", exact)                # exact kernels: the warm-up is raised to 128 frames whatever the knob says
+    wam.tune("dh_exact", exact)                # exact kernels: the warm-up is raised to 96 frames whatever the knob says
     wam.tune("dh_seg_frames", 1 << 20)
     whole = wam.process_hybrid_dynamic(x, sr)
     assert maxerr(whole, ref) <= TOL

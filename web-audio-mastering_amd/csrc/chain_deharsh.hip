@@ -608,8 +608,22 @@ __device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X
 //      guessed trajectory IS the true one and, by induction over the bins, every s is the sequential value.  Otherwise
 //      (a sum within ~1e-6 of a power of two, a tie, silence, denormals: a few frames in a thousand) the wavefront falls
 //      back to the serial walk.
-constexpr int kCross = 640;                      // crossing list capacity per frame (typically ~60)
+constexpr int kCross = 448;                      // crossing list capacity per frame (typically ~60)
 
+// DPP moves for the wavefront scans (no LDS round trip, unlike ds_bpermute): lanes without a source read 0, the identity of
+// the scans below.  row_shr:n = 0x110 + n; row_bcast:15 = 0x142 (lane 15 of every row to the next row, row mask 0xA);
+// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xC).
+template <int CTRL, int RM> __device__ __forceinline__ int dppm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, false); }
+template <int CTRL, int RM> __device__ __forceinline__ float dppm(float v) { return __int_as_float(dppm<CTRL, RM>(__float_as_int(v))); }
+template <int CTRL, int RM> __device__ __forceinline__ double dppm(double v) {
+  return __hiloint2double(dppm<CTRL, RM>(__double2hiint(v)), dppm<CTRL, RM>(__double2loint(v)));
+}
+template <int CTRL, int RM, class T> __device__ __forceinline__ void seg_step(T& v, int& fl) {
+  const T pv = dppm<CTRL, RM>(v);
+  const int pf = dppm<CTRL, RM>(fl);
+  if (!fl) v += pv;
+  fl |= pf;
+}
 // start masks: bit i = bin 16 lane + i starts a segment.  Inclusive segmented prefix sum of val[16] over the wavefront.
 template <class T>
 __device__ __forceinline__ void seg_scan16(T val[16], unsigned starts, int lane) {
@@ -618,12 +632,8 @@ __device__ __forceinline__ void seg_scan16(T val[16], unsigned starts, int lane)
   for (int i = 0; i < 16; i++) { run = ((starts >> i) & 1) ? val[i] : run + val[i]; val[i] = run; }
   T v = run;
   int fl = starts != 0;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const T pv = __shfl_up(v, d);
-    const int pf = __shfl_up(fl, d);
-    if (lane >= d) { if (!fl) v += pv; fl |= pf; }
-  }
+  seg_step<0x111, 0xF>(v, fl); seg_step<0x112, 0xF>(v, fl); seg_step<0x114, 0xF>(v, fl); seg_step<0x118, 0xF>(v, fl);
+  seg_step<0x142, 0xA>(v, fl); seg_step<0x143, 0xC>(v, fl);
   T carry = __shfl_up(v, 1);
   if (lane == 0) carry = 0;
   const int first = starts ? __builtin_ctz(starts) : 16;
@@ -645,9 +655,20 @@ __device__ __forceinline__ BandLanePlan make_band_lane_plan(const DeharshPlan& P
   return L;
 }
 
-// Returns true if the fast path verified; then bandE[b] (LDS, double holding an f32 value) is the energy of every non-empty band.
-__device__ __forceinline__ bool band_energies_scan(const float* mags, double* la, double* lR, int* lstart, double* bandE,
-                                                   const BandLanePlan& L, int lane) {
+// LDS of one wavefront behind the 1,024 f32 magnitudes: the crossing list (addend, run before it as a count of u and the
+// biased f32 exponent that defines u; then s after the crossing) and the band results.  Slots past kCross are per-lane
+// dummies, so that the per-bin stores need no branches.
+struct BandScanLds {
+  double la[kCross + 64];
+  double lS[kCross];
+  int2 lre[kCross + 64];
+  double bandE[8 + 64];
+  int lstart[8];
+};
+__device__ __forceinline__ double run_value(int r, int e) { return ldexp((double)r, e - 150); }   // r u, u = 2^(e - 127 - 23)
+
+// Returns true if the fast path verified; then W.bandE[b] (a double holding an f32 value) is the energy of every non-empty band.
+__device__ __forceinline__ bool band_energies_scan(const float* mags, BandScanLds& W, const DeharshPlan& P, const BandLanePlan& L, int lane) {
   float m[16];
 #pragma unroll
   for (int i = 0; i < 4; i++) { const float4 t = ((const float4*)(mags + 16 * lane))[i]; m[4 * i] = t.x; m[4 * i + 1] = t.y; m[4 * i + 2] = t.z; m[4 * i + 3] = t.w; }
@@ -655,7 +676,7 @@ __device__ __forceinline__ bool band_energies_scan(const float* mags, double* la
   float D[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { a[i] = (double)m[i] * (double)m[i]; D[i] = m[i] * m[i]; }
-  seg_scan16(D, L.bsm, lane);
+  seg_scan16(D, L.bsm, lane);                                     // 1. the guess
   int e[16];
   bool bad = false;
 #pragma unroll
@@ -664,69 +685,81 @@ __device__ __forceinline__ bool band_energies_scan(const float* mags, double* la
   unsigned xm = L.bsm;
 #pragma unroll
   for (int i = 0; i < 16; i++) { if (e[i] != eprev) xm |= 1u << i; eprev = e[i]; }
-  double R[16];
+  int r[16];                                                      // 2. quantised addends as counts of u (< 2^24 on a true trajectory)
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const double t = ldexp(a[i], 150 - e[i]);                    // a / u, u = 2^(E - 23), E = e - 127
-    const double r = rint(t);
+    const double t = ldexp(a[i], 150 - e[i]);                    // a / u
+    const double rd = rint(t);
     const bool cross = (xm >> i) & 1;
-    if (!cross && fabs(fabs(t - r) - 0.5) < 9.5367431640625e-07) bad = true;    // within 2^-20 of a tie (double rounding zone: 2^-29)
-    R[i] = cross ? 0.0 : ldexp(r, e[i] - 150);
+    // within 2^-20 of a rounding tie (s's parity and the reference's double rounding, zone 2^-29, decide there), or absurdly large
+    if (!cross && (fabs(t - rd) > 0.49999904632568359375 || !(t < 33554432.0))) bad = true;
+    r[i] = cross ? 0 : (int)rd;
   }
   asm volatile("" : "+v"(xm));                                    // per-bin conditions are re-derived per phase, not kept in SGPR pairs
-  seg_scan16(R, xm, lane);
+  seg_scan16(r, xm, lane);                                        // wraps mod 2^32 only on a false trajectory, whose first bad bin is still exact
   asm volatile("" : "+v"(xm));
-  const int cnt = __builtin_popcount(xm);
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int pv = __shfl_up(incl, d); if (lane >= d) incl += pv; }
-  const int base = incl - cnt;
-  const int total = __shfl(incl, 63);
-  if (total > kCross) return false;                               // uniform
-  if (lane < 8) lstart[lane] = total;
-  wave_sync();
-  double Rprev = __shfl_up(R[15], 1);
+  int base = 0, total = 0;                                        // crossings in lower lanes / in the frame: one ballot per bin slot
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    if ((xm >> i) & 1) {
-      const int idx = base + __builtin_popcount(xm & ((1u << i) - 1u));
-      la[idx] = a[i]; lR[idx] = Rprev;
-      if ((L.bsm >> i) & 1) lstart[(int)(L.bands16 >> (3 * i)) & 7] = idx;
+    const uint64_t bal = __ballot((xm >> i) & 1);
+    base = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, base));
+    total += __builtin_popcountll(bal);
+  }
+  if (total > kCross) return false;                               // uniform
+  if (lane < 8) W.lstart[lane] = total;
+  wave_sync();
+  {                                                               // 3. the crossing list
+    int rp = __shfl_up(r[15], 1), ep = __shfl_up(e[15], 1), pc = base;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const bool cross = (xm >> i) & 1;
+      const int idx = cross ? pc : kCross + lane;
+      W.la[idx] = a[i];
+      W.lre[idx] = make_int2(rp, ep);
+      pc += cross;
+      rp = r[i]; ep = e[i];
     }
-    Rprev = R[i];
+#pragma unroll 1
+    for (int b = 0; b < kBands; b++) {                            // where every non-empty band's list starts
+      const int k0 = P.band_start[b];
+      if (k0 < P.band_start[b + 1] && lane == (k0 >> 4)) W.lstart[b] = base + __builtin_popcount(xm & ((1u << (k0 & 15)) - 1u));
+    }
   }
   wave_sync();
-  if (lane < kBands) {                                            // the crossings of band `lane`, in order
-    const int ls = lstart[lane];
+  if (lane < kBands) {                                            // lane b walks band b's crossings, in order, with the exact step
+    const int ls = W.lstart[lane];
     int le = total;
-    for (int b = lane + 1; b < 8; b++) { const int t = lstart[b]; if (t < le) le = t; }
+    for (int b = lane + 1; b < 8; b++) { const int t = W.lstart[b]; if (t < le) le = t; }
     double sv = 0.0;
     for (int j = ls; j < le; j++) {
-      const double aj = la[j], rj = lR[j];
-      sv = (j == ls) ? (double)f32r(aj) : (double)f32r((sv + rj) + aj);
-      lR[j] = sv;
+      const double aj = W.la[j];
+      const int2 re = W.lre[j];
+      sv = (j == ls) ? (double)f32r(aj) : (double)f32r((sv + run_value(re.x, re.y)) + aj);
+      W.lS[j] = sv;
     }
   }
   wave_sync();
   asm volatile("" : "+v"(xm));
+  {                                                               // 4. every bin's s against the guessed binade
+    int pc = base - 1;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int idx = base + __builtin_popcount(xm & ((2u << i) - 1u)) - 1;     // the latest crossing at or before this bin
-    const double sk = lR[idx] + R[i];
-    const int ek = (int)(__float_as_uint((float)sk) >> 23) & 0xff;
-    bad |= ek != e[i];
-    if ((L.bem >> i) & 1) bandE[(int)(L.bands16 >> (3 * i)) & 7] = sk;
+    for (int i = 0; i < 16; i++) {
+      pc += (xm >> i) & 1;                                        // the latest crossing at or before this bin
+      const double sk = W.lS[pc] + run_value(r[i], e[i]);
+      const int ek = (int)(__float_as_uint((float)sk) >> 23) & 0xff;
+      bad |= ek != e[i];
+      W.bandE[((L.bem >> i) & 1) ? (int)(L.bands16 >> (3 * i)) & 7 : 8 + lane] = sk;
+    }
   }
   wave_sync();
   return __ballot(bad) == 0;
 }
 
-
 __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
                                                        float* __restrict__ band_rms, double pre_gain, int scan_sums) {
   __shared__ dcx buf[4][kWaveBuf];
-  static_assert(sizeof(float) * kBins + sizeof(double) * (2 * kCross + 8) + sizeof(int) * 8 <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
+  static_assert(sizeof(float) * kBins + sizeof(BandScanLds) <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
@@ -766,17 +799,14 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; j++) { const int k = lane + 64 * j; mags[k] = mk[j]; mags[k == 0 ? 512 : kM - k] = mm[j]; }
     wave_sync();
-    double* la = (double*)(mags + kBins);                          // the rest of the wavefront's buffer: crossing lists, band results
-    double* lR = la + kCross;
-    double* bandE = lR + kCross;
-    int* lstart = (int*)(bandE + 8);
+    BandScanLds& W = *(BandScanLds*)(mags + kBins);                // the rest of the wavefront's buffer: crossing list, band results
     BandLanePlan Lf = L;                                           // opaque per frame: the 48 per-bin conditions derived from the masks are
     asm volatile("" : "+v"(Lf.bsm), "+v"(Lf.bem), "+v"(Lf.bands16));   // loop-invariant, and hoisted they live in ~100 SGPRs across the transform
-    const bool fast = scan_sums && band_energies_scan(mags, la, lR, lstart, bandE, Lf, lane);
+    const bool fast = scan_sums && band_energies_scan(mags, W, P, Lf, lane);
     if (lane < kBands) {                                           // bandEnergies[b] += mag * mag in bin order, a Float32Array (:327-339)
       float be = 0.0f;
       const int k1 = fast ? 0 : P.band_start[lane + 1];              // the serial walk when the scan did not verify
-      if (fast && P.cnt[lane] > 0) be = (float)bandE[lane];
+      if (fast && P.cnt[lane] > 0) be = (float)W.bandE[lane];
       int k = P.band_start[lane];
       for (; k + 8 <= k1; k += 8) {                                // loads up front: the adds are the dependent chain
         float m8[8];
@@ -1009,8 +1039,9 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
                plan.as<DeharshPlan>(), nchan, gdb.as<float>());
   }
   // segments are walked by wavefronts, four to a workgroup: aim at ~16 k wavefronts (12 are resident per CU)
-  // exact mode: the resonance EMA must forget its start to below one f32 rounding (0.7^128 = 1.5e-20), not to ~1e-7
-  const int64_t warm = exact && tuning().dh_warm_frames < 128 ? 128 : tuning().dh_warm_frames;
+  // exact mode: the resonance EMA (an f32 state) must forget its start far below one f32 rounding, not to ~1e-7:
+  // 0.7^96 = 1.4e-15 is 2e-8 of an ulp, the odds per bin and segment that the warm-started state rounds differently
+  const int64_t warm = exact && tuning().dh_warm_frames < 96 ? 96 : tuning().dh_warm_frames;
   const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, exact ? 8192 : 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
   if (exact) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
