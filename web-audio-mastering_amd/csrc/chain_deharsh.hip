@@ -548,14 +548,18 @@ __device__ __forceinline__ double quad_xor1_d(double v) {
   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-// tables in global memory (double): twl[64 (k - 1) + lane] = W1024^(lane k), twq[16 q + k] = W64^(q k), twB[k] = W2048^k
+// tables (double): twl[64 (k - 1) + lane] = W1024^(lane k), twq[16 q + k] = W64^(q k), twB[k] = W2048^k.  The kernels keep twq and
+// twl's k = 1..8 in LDS (what it has room for beside the exchange buffers) and read twB from global memory.
 struct WaveTwD { const dcx* l; const dcx* q; };
 template <bool INV>
 __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD& T) {
   const int lane = lane_id(), q = lane & 3;
   dft16_d<INV>(v);
+  dcx w[9];                                                       // W1024^(lane k): k = 1..8 from the table (LDS), 9..15 as W^(8 lane) W^((k-8) lane)
 #pragma unroll
-  for (int k = 1; k < 16; k++) { const dcx w = T.l[64 * (k - 1) + lane]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
+  for (int k = 1; k <= 8; k++) { w[k] = T.l[64 * (k - 1) + lane]; v[k] = INV ? dmulc(v[k], w[k]) : dmul(v[k], w[k]); }
+#pragma unroll
+  for (int k = 9; k < 16; k++) { const dcx wk = dmul(w[8], w[k - 8]); v[k] = INV ? dmulc(v[k], wk) : dmul(v[k], wk); }
 #pragma unroll
   for (int k = 0; k < 16; k++) ex[k * kExRow + lane] = v[k];
   wave_sync();
@@ -759,7 +763,10 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
                                                        float* __restrict__ band_rms, double pre_gain, int scan_sums) {
   __shared__ dcx buf[4][kWaveBuf];
+  __shared__ dcx tws[kTwq + 8 * 64];                              // W64^(qk), then W1024^(lane k) for k = 1..8
   static_assert(sizeof(float) * kBins + sizeof(BandScanLds) <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
+  for (int i = threadIdx.x; i < kTwq + 8 * 64; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
+  __syncthreads();
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
@@ -773,7 +780,9 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     if (f >= P.nframes) break;
     dcx v[16];
     const dcx* twf = reload_each_tile(twd);                       // tables re-read per frame, not hoisted into ~200 registers
-    const WaveTwD T{ twf, twf + kTwl };
+    int toff = 0;
+    asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
+    const WaveTwD T{ tws + toff + kTwq, tws + toff };
     const dcx* twB = twf + kTwl + kTwq;
     load_frame_d(x, f * kHop, reload_each_tile(wing), pre_gain, v);
     wave_sync();
@@ -827,7 +836,10 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
                                                        const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
                                                        int64_t seg_frames, int64_t nseg, int64_t warm) {
   __shared__ dcx buf[4][kWaveBuf];
+  __shared__ dcx tws[kTwq + 8 * 64];                              // W64^(qk), then W1024^(lane k) for k = 1..8 (see k_dh_bands_x)
   __shared__ float bgs[4][8];
+  for (int i = threadIdx.x; i < kTwq + 8 * 64; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
+  __syncthreads();
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
@@ -868,8 +880,10 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     // global loads) they would occupy ~200 registers and force one wavefront per SIMD
     const float* win = reload_each_tile(wing);
     const dcx* twf = reload_each_tile(twd);
-    WaveTwD T{ twf, twf + kTwl };
-    const dcx* twB = twf + kTwl + kTwq;
+    int toff = 0;
+    asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
+    WaveTwD T{ tws + toff + kTwq, tws + toff };
+
     load_frame_d(x, f * kHop, win, pre_gain, v);
     if (lane < kBands) bg[lane] = band_gdb[(chan * F + f) * kBands + lane];
     wave_sync();
@@ -890,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       if (res > 0) gdb += -3.0 * (double)res * 0.2;
       return (double)f32r(exp_fast(gdb / 20 * 2.30258509299404568402));   // 10^(gdb / 20); gains is a Float32Array (:320,:381)
     };
+    const dcx* twB = twf + kTwl + kTwq;                            // (W2048 from LDS costs this kernel 600 spilled VGPRs: left in global memory)
 #pragma unroll 1                                                   // rolled: unrolled, the eight bodies' loads are hoisted and spill
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
@@ -925,7 +940,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
     twf = reload_each_tile(twf);
-    T = WaveTwD{ twf, twf + kTwl };
+    asm volatile("" : "+s"(toff));
+    T = WaveTwD{ tws + toff + kTwq, tws + toff };
     fft1024_wave_d<true>(v, zw, T);
     win = reload_each_tile(win);
     wave_sync();                                                   // the exchange's reads precede the float writes below (other layout)
