@@ -551,13 +551,40 @@ __device__ __forceinline__ double quad_xor1_d(double v) {
 // tables (double): twl[64 (k - 1) + lane] = W1024^(lane k), twq[16 q + k] = W64^(q k), twB[k] = W2048^k.  The kernels keep twq and
 // twl's k = 1..8 in LDS (what it has room for beside the exchange buffers) and read twB from global memory.
 struct WaveTwD { const dcx* l; const dcx* q; };
+constexpr int kTwlLds = 6;                                         // W1024^(lane k) kept in LDS for k = 1..6
+constexpr int kTwsLds = kTwq + kTwlLds * 64;                       // dcx entries: W64^(qk), then those
+// The analysis / synthesis window.  The f32 Hann table is symmetric (win[i] == win[2047 - i], checked on the host when the
+// table is built), so its first half fits the LDS beside the twiddles: 512 float2; otherwise the kernels read the full
+// table from global memory.
+struct WinSrc { const float* g; const float2* h; int sym; };
+template <bool LOW>                                                // LOW: m < 512 known at compile time
+__device__ __forceinline__ float2 window_pair(const WinSrc& W, int m) {   // (win[2 m], win[2 m + 1])
+  if (!W.sym) return ((const float2*)W.g)[m];
+  if (LOW) return W.h[m];
+  const float2 t = W.h[kM - 1 - m];
+  return make_float2(t.y, t.x);
+}
+__device__ __forceinline__ float2 window_pair_any(const WinSrc& W, int m) {
+  if (!W.sym) return ((const float2*)W.g)[m];
+  const bool low = m < kM / 2;
+  const float2 t = W.h[low ? m : kM - 1 - m];
+  return low ? t : make_float2(t.y, t.x);
+}
+__device__ __forceinline__ void load_tables_lds(dcx* tws, float2* winh, const dcx* __restrict__ twd, const float* __restrict__ wing) {
+  for (int i = threadIdx.x; i < kTwsLds; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
+  for (int i = threadIdx.x; i < kM / 2; i += 256) winh[i] = ((const float2*)wing)[i];
+  __syncthreads();
+}
 template <bool INV>
 __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD& T) {
   const int lane = lane_id(), q = lane & 3;
   dft16_d<INV>(v);
-  dcx w[9];                                                       // W1024^(lane k): k = 1..8 from the table (LDS), 9..15 as W^(8 lane) W^((k-8) lane)
+  dcx w[9];                                                       // W1024^(lane k): k = 1..6 from the table (LDS), then W^7 = W^4 W^3, W^8 = W^4 W^4,
+#pragma unroll                                                    // W^(8 + j) = W^8 W^j: at most three products deep
+  for (int k = 1; k <= kTwlLds; k++) w[k] = T.l[64 * (k - 1) + lane];
+  w[7] = dmul(w[4], w[3]); w[8] = dmul(w[4], w[4]);
 #pragma unroll
-  for (int k = 1; k <= 8; k++) { w[k] = T.l[64 * (k - 1) + lane]; v[k] = INV ? dmulc(v[k], w[k]) : dmul(v[k], w[k]); }
+  for (int k = 1; k <= 8; k++) v[k] = INV ? dmulc(v[k], w[k]) : dmul(v[k], w[k]);
 #pragma unroll
   for (int k = 9; k < 16; k++) { const dcx wk = dmul(w[8], w[k - 8]); v[k] = INV ? dmulc(v[k], wk) : dmul(v[k], wk); }
 #pragma unroll
@@ -586,12 +613,20 @@ __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
   p.t = dmul(dcx{ d.y, -d.x }, w);
   return p;
 }
-// the windowed frame is a Float32Array in the reference (fft.js:30,44): load_frame()'s f32 product is that store; widened here
-__device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_t pos, const float* __restrict__ win, double pre_gain, dcx v[16]) {
+// the windowed frame is a Float32Array in the reference (fft.js:30,44): the f32 product IS that store (exact product, one rounding)
+__device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_t pos, const WinSrc& W, double pre_gain, dcx v[16]) {
   float2 vf[16];
-  load_frame(x, pos, win, pre_gain, vf);
+  load_frame_raw(x, pos, vf);
+  const int lane = lane_id();
 #pragma unroll
-  for (int r = 0; r < 16; r++) v[r] = dcx{ (double)vf[r].x, (double)vf[r].y };
+  for (int r = 0; r < 16; r++) {
+    float v0 = vf[r].x, v1 = vf[r].y;
+    if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
+    if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
+    if (!(v1 == v1)) v1 = 0.0f;
+    const float2 w = r < 8 ? window_pair<true>(W, 64 * r + lane) : window_pair<false>(W, 64 * r + lane);
+    v[r] = dcx{ (double)(v0 * w.x), (double)(v1 * w.y) };
+  }
 }
 // magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
 __device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X.y * X.y)); }
@@ -761,12 +796,12 @@ __device__ __forceinline__ bool band_energies_scan(const float* mags, BandScanLd
 
 __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
-                                                       float* __restrict__ band_rms, double pre_gain, int scan_sums) {
+                                                       float* __restrict__ band_rms, double pre_gain, int scan_sums, int win_sym) {
   __shared__ dcx buf[4][kWaveBuf];
-  __shared__ dcx tws[kTwq + 8 * 64];                              // W64^(qk), then W1024^(lane k) for k = 1..8
+  __shared__ dcx tws[kTwsLds];
+  __shared__ float2 winh[kM / 2];
   static_assert(sizeof(float) * kBins + sizeof(BandScanLds) <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
-  for (int i = threadIdx.x; i < kTwq + 8 * 64; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
-  __syncthreads();
+  load_tables_lds(tws, winh, twd, wing);
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
@@ -784,7 +819,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
     const WaveTwD T{ tws + toff + kTwq, tws + toff };
     const dcx* twB = twf + kTwl + kTwq;
-    load_frame_d(x, f * kHop, reload_each_tile(wing), pre_gain, v);
+    const WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
+    load_frame_d(x, f * kHop, Wn, pre_gain, v);
     wave_sync();
     fft1024_wave_d<false>(v, z, T);
 #pragma unroll
@@ -834,12 +870,12 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
 __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                        const DeharshPlan* __restrict__ dp, const dcx* __restrict__ twd,
                                                        const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
-                                                       int64_t seg_frames, int64_t nseg, int64_t warm) {
+                                                       int64_t seg_frames, int64_t nseg, int64_t warm, int win_sym) {
   __shared__ dcx buf[4][kWaveBuf];
-  __shared__ dcx tws[kTwq + 8 * 64];                              // W64^(qk), then W1024^(lane k) for k = 1..8 (see k_dh_bands_x)
+  __shared__ dcx tws[kTwsLds];
+  __shared__ float2 winh[kM / 2];
   __shared__ float bgs[4][8];
-  for (int i = threadIdx.x; i < kTwq + 8 * 64; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
-  __syncthreads();
+  load_tables_lds(tws, winh, twd, wing);
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
@@ -878,13 +914,13 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     dcx v[16];
     // the tables are re-read every frame through opaque pointers: hoisted out of the frame loop (they are loop-invariant
     // global loads) they would occupy ~200 registers and force one wavefront per SIMD
-    const float* win = reload_each_tile(wing);
     const dcx* twf = reload_each_tile(twd);
     int toff = 0;
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
     WaveTwD T{ tws + toff + kTwq, tws + toff };
 
-    load_frame_d(x, f * kHop, win, pre_gain, v);
+    WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
+    load_frame_d(x, f * kHop, Wn, pre_gain, v);
     if (lane < kBands) bg[lane] = band_gdb[(chan * F + f) * kBands + lane];
     wave_sync();
     fft1024_wave_d<false>(v, zw, T);
@@ -943,15 +979,15 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     asm volatile("" : "+s"(toff));
     T = WaveTwD{ tws + toff + kTwq, tws + toff };
     fft1024_wave_d<true>(v, zw, T);
-    win = reload_each_tile(win);
+    Wn = WinSrc{ reload_each_tile(wing), winh + toff, win_sym };
     wave_sync();                                                   // the exchange's reads precede the float writes below (other layout)
     float2* yf = (float2*)zw;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int m = ob + 16 * j;
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
-      const float2 ws = ((const float2*)(win + kN))[m];            // window / 1024 (exact scaling): the inverse's 1 / N folded in
-      yf[m] = make_float2(f32r(v[j].x * (double)ws.x), f32r(v[j].y * (double)ws.y));
+      const float2 ws = window_pair_any(Wn, m);                    // the inverse's 1 / N is an exact scaling: applied to the window
+      yf[m] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
     }
     wave_sync();
     const float* yw = (const float*)zw;
@@ -1018,15 +1054,16 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   int rc;
   rc = plan.alloc(sizeof(dp)); if (rc) return rc;
   rc = twb.alloc(sizeof(float2) * (kTw1 + kTwB)); if (rc) return rc;
-  rc = winb.alloc(sizeof(float) * 2 * kN); if (rc) return rc;    // window, then window / 1024 (exact kernels' synthesis)
+  rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   std::vector<float2> tw(kTw1 + kTwB);
-  std::vector<float> win(2 * kN);
+  std::vector<float> win(kN);
   for (int k = 0; k < kTw1; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int k = 0; k < kTwB; k++) { const double a = -2 * M_PI * k / kN; tw[kTw1 + k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
   for (int i = 0; i < kN; i++) win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / (kN - 1))));     // utils.js:98-104
-  for (int i = 0; i < kN; i++) win[kN + i] = win[i] * (1.0f / kM);
+  int win_sym = 1;                                                // the exact kernels keep half the table in LDS if it mirrors (it does with glibc's cos)
+  for (int i = 0; i < kN / 2; i++) if (win[i] != win[kN - 1 - i]) win_sym = 0;
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
@@ -1048,7 +1085,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     // the exact kernel's per-workgroup set-up (band plan of every lane) wants long-lived workgroups: ~8 k in all (512 are resident)
     int64_t gxx = 8192 / nchan; if (gxx < 1) gxx = 1; if (gxx > ngroups) gxx = ngroups;
     if (exact) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gxx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
-                          winb.as<float>(), rms.as<float>(), pre_gain, (int)(tuning().dh_scan_sums != 0));
+                          winb.as<float>(), rms.as<float>(), pre_gain, (int)(tuning().dh_scan_sums != 0), win_sym);
     else WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
@@ -1061,7 +1098,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, exact ? 8192 : 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
   if (exact) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
-                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
+                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm, win_sym);
   else WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                   winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return
