@@ -35,7 +35,7 @@ int wam_profile_read(char* buf, size_t cap);
  * "sc_warm_tiles", "lim_warm_tiles"; "reset" restores the defaults.  Process-wide; meant for tests that make short
  * fixtures cross segment seams, and for tuning runs.
  * "dh_exact" (default 1) selects the de-harsh kernels: 1 = every Float32Array store of the reference reproduced (double
- * transform, sequential f32 band sums); 0 = float32 kernels, 2.3x faster, ~1e-7 on the stage's output, which the soft
+ * transform, sequential f32 band sums); 0 = float32 kernels, 1.9x faster, ~1e-7 on the stage's output, which the soft
  * clipper can amplify past the 1e-5 PCM bar on hard-driven masters (deviations). */
 int wam_tune(const char* key, int64_t value);
 
