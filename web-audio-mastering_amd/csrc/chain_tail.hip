@@ -18,8 +18,8 @@ __device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
 __device__ __forceinline__ double block_excl_sum(double v, double& total, double* lds) {
   const int lane = lane_id(), wave = wave_id();
   double inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  inc += dpp_d<0x111, 0xF>(0.0, inc); inc += dpp_d<0x112, 0xF>(0.0, inc); inc += dpp_d<0x114, 0xF>(0.0, inc); inc += dpp_d<0x118, 0xF>(0.0, inc);
+  inc += dpp_d<0x142, 0xA>(0.0, inc); inc += dpp_d<0x143, 0xC>(0.0, inc);          // rows, then the row aggregates (wam_device.hpp)
   if (lane == 63) lds[wave] = inc;
   __syncthreads();
   double off = 0, tot = 0;

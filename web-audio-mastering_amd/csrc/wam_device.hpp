@@ -165,6 +165,28 @@ __device__ __forceinline__ double wave_sum_ordered(double v) {   // fixed tree: 
   return v;
 }
 
+// DPP moves for the wavefront scans: no LDS round trip (ds_bpermute, which __shfl_up compiles to, takes one per 32 bits) and
+// no lane arithmetic; a lane without a source keeps `old`, which the callers set to the identity of their scan.
+// row_shr:n = 0x110 + n (within rows of 16 lanes); row_bcast:15 = 0x142 with row mask 0xA (lane 15 of rows 0 / 2 to rows
+// 1 / 3); row_bcast:31 = 0x143 with row mask 0xC (lane 31 to rows 2 and 3); wave_shr:1 = 0x138 (lane l - 1).
+template <int CTRL, int RM> __device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, RM, 0xF, false));
+}
+template <int CTRL, int RM> __device__ __forceinline__ double dpp_d(double old, double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, RM, 0xF, false),
+                          __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, RM, 0xF, false));
+}
+// Inclusive scan of affine maps x -> al x + be over the wavefront (lane l: the composition of lanes 0..l, lower lanes
+// applied first): Hillis-Steele inside the rows, then the row aggregates by two broadcasts.
+template <int CTRL, int RM> __device__ __forceinline__ void affine_step(double& al, double& be) {
+  const double ta = dpp_d<CTRL, RM>(1.0, al), tb = dpp_d<CTRL, RM>(0.0, be);
+  be = al * tb + be; al = al * ta;
+}
+__device__ __forceinline__ void wave_scan_affine(double& al, double& be) {
+  affine_step<0x111, 0xF>(al, be); affine_step<0x112, 0xF>(al, be); affine_step<0x114, 0xF>(al, be); affine_step<0x118, 0xF>(al, be);
+  affine_step<0x142, 0xA>(al, be); affine_step<0x143, 0xC>(al, be);
+}
+
 __device__ __forceinline__ void mat2_mul(const double a[4], const double b[4], double o[4]) {
   o[0] = a[0] * b[0] + a[1] * b[2]; o[1] = a[0] * b[1] + a[1] * b[3];
   o[2] = a[2] * b[0] + a[3] * b[2]; o[3] = a[2] * b[1] + a[3] * b[3];
@@ -192,6 +214,8 @@ __device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane)
 __device__ __forceinline__ void scan2(double& e0, double& e1, const Biquad& q, const double P[4],
                                       double& S0, double& S1, double* lds) {
   const int lane = lane_id(), wave = wave_id();
+  // (Hillis-Steele over the whole wavefront: the row-wise DPP form of biquad_chunk_lds needs the M^lane table in LDS for its
+  // broadcast steps, which this register variant does not have)
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const int d = 1 << k;
@@ -199,8 +223,7 @@ __device__ __forceinline__ void scan2(double& e0, double& e1, const Biquad& q, c
     if (lane >= d) { e0 += q.Mp[k][0] * t0 + q.Mp[k][1] * t1; e1 += q.Mp[k][2] * t0 + q.Mp[k][3] * t1; }
   }
   if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
-  double x0 = __shfl_up(e0, 1), x1 = __shfl_up(e1, 1);
-  if (lane == 0) { x0 = 0; x1 = 0; }
+  const double x0 = dpp_d<0x138, 0xF>(0.0, e0), x1 = dpp_d<0x138, 0xF>(0.0, e1);
   __syncthreads();
   double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
 #pragma unroll
@@ -268,15 +291,22 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
   double e0 = p1, e1 = p2;
   const int lane = lane_id(), wave = wave_id();
   const double S0 = Slds[0], S1 = Slds[1];           // read before the barrier below; rewritten after it
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const int d = 1 << k;
-    const double t0 = __shfl_up(e0, d), t1 = __shfl_up(e1, d);
-    if (lane >= d) { e0 += q.Mp[k][0] * t0 + q.Mp[k][1] * t1; e1 += q.Mp[k][2] * t0 + q.Mp[k][3] * t1; }
+  // weighted prefix sum of the end states: inside the rows of 16 lanes by DPP row shifts (uniform powers M^1, M^2, M^4, M^8) ...
+#define WAM_SCAN2_ROW(K, CTRL) { const double t0 = dpp_d<CTRL, 0xF>(0.0, e0), t1 = dpp_d<CTRL, 0xF>(0.0, e1); \
+    e0 += q.Mp[K][0] * t0 + q.Mp[K][1] * t1; e1 += q.Mp[K][2] * t0 + q.Mp[K][3] * t1; }
+  WAM_SCAN2_ROW(0, 0x111) WAM_SCAN2_ROW(1, 0x112) WAM_SCAN2_ROW(2, 0x114) WAM_SCAN2_ROW(3, 0x118)
+  {
+    // ... then the aggregate of the row(s) below reaches a lane through M^(distance to that aggregate's lane): M^((lane & 15) + 1) for
+    // the previous row's lane 15, M^(lane - 31) for lane 31 - both entries of the M^lane table
+    const double* Pa = Plds + 4 * ((lane & 15) + 1);
+    const double ta0 = dpp_d<0x142, 0xA>(0.0, e0), ta1 = dpp_d<0x142, 0xA>(0.0, e1);
+    e0 += Pa[0] * ta0 + Pa[1] * ta1; e1 += Pa[2] * ta0 + Pa[3] * ta1;
+    const double* Pb = Plds + 4 * (lane >= 32 ? lane - 31 : 0);
+    const double tb0 = dpp_d<0x143, 0xC>(0.0, e0), tb1 = dpp_d<0x143, 0xC>(0.0, e1);
+    e0 += Pb[0] * tb0 + Pb[1] * tb1; e1 += Pb[2] * tb0 + Pb[3] * tb1;
   }
   if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
-  double x0 = __shfl_up(e0, 1), x1 = __shfl_up(e1, 1);
-  if (lane == 0) { x0 = 0; x1 = 0; }
+  const double x0 = dpp_d<0x138, 0xF>(0.0, e0), x1 = dpp_d<0x138, 0xF>(0.0, e1);
   __syncthreads();
   double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
 #pragma unroll
@@ -303,15 +333,12 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
 // ---- first-order scan ----------------------------------------------------------
 __device__ __forceinline__ void scan1(double& e, const OnePole& q, double Pl, double& S, double* lds) {
   const int lane = lane_id(), wave = wave_id();
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const int d = 1 << k;
-    const double t = __shfl_up(e, d);
-    if (lane >= d) e += q.Mp[k] * t;
-  }
+  // lane l's chunk is the affine map x -> c^C x + e: the wavefront scan of those maps (rows by DPP, row aggregates by
+  // broadcasts) leaves the weighted prefix sum in `be`; its multiplier `al` = c^(C (l + 1)) is what the broadcast steps need
+  double al = q.Mp[0];
+  wave_scan_affine(al, e);
   if (lane == 63) lds[wave] = e;
-  double x = __shfl_up(e, 1);
-  if (lane == 0) x = 0;
+  const double x = dpp_d<0x138, 0xF>(0.0, e);
   __syncthreads();
   double w = S, my = S;
 #pragma unroll
@@ -341,15 +368,9 @@ __device__ __forceinline__ void onepole_chunk(double u[C], const OnePole& q, dou
 template <bool CLAMP1 = false>
 __device__ __forceinline__ double scan_affine(double al, double be, double& S, double* lds) {
   const int lane = lane_id(), wave = wave_id();
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const int d = 1 << k;
-    const double ta = __shfl_up(al, d), tb = __shfl_up(be, d);
-    if (lane >= d) { be = al * tb + be; al = al * ta; }
-  }
+  wave_scan_affine(al, be);
   if (lane == 63) { lds[2 * wave] = al; lds[2 * wave + 1] = be; }
-  double xa = __shfl_up(al, 1), xb = __shfl_up(be, 1);
-  if (lane == 0) { xa = 1; xb = 0; }
+  const double xa = dpp_d<0x138, 0xF>(1.0, al), xb = dpp_d<0x138, 0xF>(0.0, be);
   __syncthreads();
   double w = S, my = S;
 #pragma unroll
@@ -473,18 +494,15 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
         be = c * (be - an) + an;
         al = c * al;
       }
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const int d = 1 << k;
-        v2f ta, tb;
-        ta.x = __shfl_up(al.x, d); ta.y = __shfl_up(al.y, d); tb.x = __shfl_up(be.x, d); tb.y = __shfl_up(be.y, d);
-        if (lane >= d) { be = al * tb + be; al = al * ta; }
-      }
+#define WAM_PRE_STEP(CTRL, RM) { v2f ta, tb; ta.x = dpp_f<CTRL, RM>(1.0f, al.x); ta.y = dpp_f<CTRL, RM>(1.0f, al.y); \
+        tb.x = dpp_f<CTRL, RM>(0.0f, be.x); tb.y = dpp_f<CTRL, RM>(0.0f, be.y); be = al * tb + be; al = al * ta; }
+      WAM_PRE_STEP(0x111, 0xF) WAM_PRE_STEP(0x112, 0xF) WAM_PRE_STEP(0x114, 0xF) WAM_PRE_STEP(0x118, 0xF)
+      WAM_PRE_STEP(0x142, 0xA) WAM_PRE_STEP(0x143, 0xC)
       float* ldsf = (float*)lds + 16 * pre;                       // the slot's 16 doubles = two regions of 16 floats, one per pass
       if (lane == 63) { ldsf[4 * wave] = al.x; ldsf[4 * wave + 1] = al.y; ldsf[4 * wave + 2] = be.x; ldsf[4 * wave + 3] = be.y; }
       v2f xa, xb;
-      xa.x = __shfl_up(al.x, 1); xa.y = __shfl_up(al.y, 1); xb.x = __shfl_up(be.x, 1); xb.y = __shfl_up(be.y, 1);
-      if (lane == 0) { xa = (v2f){ 1.0f, 1.0f }; xb = (v2f){ 0.0f, 0.0f }; }
+      xa.x = dpp_f<0x138, 0xF>(1.0f, al.x); xa.y = dpp_f<0x138, 0xF>(1.0f, al.y);
+      xb.x = dpp_f<0x138, 0xF>(0.0f, be.x); xb.y = dpp_f<0x138, 0xF>(0.0f, be.y);
       __syncthreads();
       v2f w = Sin, my = Sin;
 #pragma unroll
@@ -519,15 +537,12 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
     // they are the solution, and S1 / S2 already hold the carries of that scan.  (Also the barrier that lets lds be rewritten.)
     if (it > 0 && !__syncthreads_or((int)(m != pm))) break;
     pm = m;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int d = 1 << k;
-      const double ta1 = __shfl_up(al1, d), tb1 = __shfl_up(be1, d), ta2 = __shfl_up(al2, d), tb2 = __shfl_up(be2, d);
-      if (lane >= d) { be1 = al1 * tb1 + be1; al1 = al1 * ta1; be2 = al2 * tb2 + be2; al2 = al2 * ta2; }
-    }
+#define WAM_PAIR_STEP(CTRL, RM) { affine_step<CTRL, RM>(al1, be1); affine_step<CTRL, RM>(al2, be2); }
+    WAM_PAIR_STEP(0x111, 0xF) WAM_PAIR_STEP(0x112, 0xF) WAM_PAIR_STEP(0x114, 0xF) WAM_PAIR_STEP(0x118, 0xF)
+    WAM_PAIR_STEP(0x142, 0xA) WAM_PAIR_STEP(0x143, 0xC)
     if (lane == 63) { lds[4 * wave] = al1; lds[4 * wave + 1] = be1; lds[4 * wave + 2] = al2; lds[4 * wave + 3] = be2; }
-    double xa1 = __shfl_up(al1, 1), xb1 = __shfl_up(be1, 1), xa2 = __shfl_up(al2, 1), xb2 = __shfl_up(be2, 1);
-    if (lane == 0) { xa1 = 1; xb1 = 0; xa2 = 1; xb2 = 0; }
+    const double xa1 = dpp_d<0x138, 0xF>(1.0, al1), xb1 = dpp_d<0x138, 0xF>(0.0, be1);
+    const double xa2 = dpp_d<0x138, 0xF>(1.0, al2), xb2 = dpp_d<0x138, 0xF>(0.0, be2);
     __syncthreads();
     double w1 = S1_in, w2 = S2_in, my1 = S1_in, my2 = S2_in;
 #pragma unroll
@@ -644,7 +659,7 @@ __device__ __forceinline__ void prev_ctx(const float last[K], float prev[K], flo
   float* cur = site + parity * kWaves * K;
   const float* old = site + (parity ^ 1) * kWaves * K;
 #pragma unroll
-  for (int k = 0; k < K; k++) prev[k] = __shfl_up(last[k], 1);
+  for (int k = 0; k < K; k++) prev[k] = dpp_f<0x138, 0xF>(0.0f, last[k]);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < K; k++) cur[wave * K + k] = last[k];
