@@ -38,10 +38,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, do_meter ? mp->hop : 0, do_meter ? mp->nhops : 0);
   if (wave_id() == 0) {
-    biquad_lane_power(fp->hpf30, lane, Pl[kFHpf][lane]);
+    biquad_lane_power_table(fp->hpf30, lane, &Pl[kFHpf][0][0]);
 #pragma unroll
-    for (int b = 0; b < 6; b++) if (b < fp->n_eq) biquad_lane_power(fp->eq[b], lane, Pl[kFEq0 + b][lane]);
-    biquad_lane_power(fp->side_hp, lane, Pl[kFSide][lane]);
+    for (int b = 0; b < 6; b++) if (b < fp->n_eq) biquad_lane_power_table(fp->eq[b], lane, &Pl[kFEq0 + b][0][0]);
+    biquad_lane_power_table(fp->side_hp, lane, &Pl[kFSide][0][0]);
   }
   for (int i = threadIdx.x; i < (NCH * 9 + 1) * 2; i += kThreads) Sl[i >> 1][i & 1] = 0;
   const double Plpf = onepole_lane_power(fp->lpf18, lane);

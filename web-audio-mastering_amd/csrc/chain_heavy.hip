@@ -23,9 +23,11 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
   const float* x = in + chan * n;
   float* y = out + chan * n;
   LdsSlots slots(lds_scan);
-  double P1[4];
-  biquad_lane_power(hp->exc_hp, lane_id(), P1);
-  double Sa[2] = {0, 0}, Sb[2] = {0, 0};
+  __shared__ double Ptab[64][4];                 // M^lane of the high-pass (the scans' broadcast steps index it, wam_device.hpp)
+  __shared__ double Sst[2][2];                   // tile carries of the two cascaded instances
+  if (wave_id() == 0) biquad_lane_power_table(hp->exc_hp, lane_id(), &Ptab[0][0]);
+  if (threadIdx.x < 4) Sst[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+  __syncthreads();
   const double mix = 0.15 / 100, drive = 0.5, bias = 0.2;     // constants.js:36-42, exciter.js:88
   // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early: the only state is two 6 kHz high-passes
   const int64_t ntiles = (n + kTile - 1) / kTile;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < C; k++) { xin[k] = v[k]; d[k] = v[k]; }
     double s0, s1;
-    biquad_chunk(d, pv[1], pv[0], P.exc_hp, P1, Sa[0], Sa[1], slots.next(), s0, s1);
+    biquad_chunk_lds(d, pv[1], pv[0], P.exc_hp, &Ptab[0][0], Sst[0], slots.next(), s0, s1);
     double ea, eb;
     biquad_extra2(d, xin, va, vb, P.exc_hp, ea, eb);
     double f1[C];
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     for (int k = 0; k < C; k++) { f1[k] = (double)f32r(d[k]); d[k] = f1[k]; }
     const double f1a = (double)f32r(ea), f1b = (double)f32r(eb);
     double u0, u1;
-    biquad_chunk(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, P1, Sb[0], Sb[1], slots.next(), u0, u1);
+    biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, &Ptab[0][0], Sst[1], slots.next(), u0, u1);
     double ga, gb;
     biquad_extra2(d, f1, f1a, f1b, P.exc_hp, ga, gb);
     // filtered[i-1 .. i+2] around each sample; out-of-range reads are 0 (exciter.js:162-184)
@@ -135,8 +137,8 @@ __global__ void k_warm_env(const unsigned* __restrict__ winpeak, int ntracks, in
 struct SplitState { double P[4][64][4]; double S[8][2]; };      // lives in LDS
 __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, const Biquad& hp1, const Biquad& lp2, const Biquad& hp2) {
   if (wave_id() == 0) {
-    biquad_lane_power(lp1, lane_id(), st.P[0][lane_id()]); biquad_lane_power(hp1, lane_id(), st.P[1][lane_id()]);
-    biquad_lane_power(lp2, lane_id(), st.P[2][lane_id()]); biquad_lane_power(hp2, lane_id(), st.P[3][lane_id()]);
+    biquad_lane_power_table(lp1, lane_id(), &st.P[0][0][0]); biquad_lane_power_table(hp1, lane_id(), &st.P[1][0][0]);
+    biquad_lane_power_table(lp2, lane_id(), &st.P[2][0][0]); biquad_lane_power_table(hp2, lane_id(), &st.P[3][0][0]);
   }
   if (threadIdx.x < 16) st.S[threadIdx.x >> 1][threadIdx.x & 1] = 0;
   __syncthreads();

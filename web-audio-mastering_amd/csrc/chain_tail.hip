@@ -420,8 +420,10 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
   // time segment (blockIdx.y); the only carried state is the fused meter's filters and six samples of context
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, mp ? mp->hop : 0, mp ? mp->nhops : 0);
-  MeterState ms;
-  if (mp) meter_init(ms, *mp, sg.Tw * kTile, &sg);
+  __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
+  MeterStateL ms;
+  if (mp) meter_init_l(ms, *mp, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
+  __syncthreads();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
       const float lo[3] = { o[C - 3], o[C - 2], o[C - 1] };
       float op[3];
       prev_ctx<3>(lo, op, ctx[1], par, t == sg.Tw);
-      meter_chunk(o, op, base, tile_base, n, *mp, ms, lds_meter, hopsums + chan * hop_stride);
+      meter_chunk_l(o, op, base, tile_base, n, *mp, ms, lds_meter, hopsums + chan * hop_stride);
     }
   }
   if (mp) meter_finish(ms, lds_meter, peaks + chan);

@@ -23,8 +23,10 @@ __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in
   double* hs = hopsums + chan * hop_stride;
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, pl.hop, pl.nhops);
-  MeterState m;
-  meter_init(m, pl, sg.Tw * kTile, &sg);
+  __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
+  MeterStateL m;
+  meter_init_l(m, pl, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
+  __syncthreads();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in
     const float last[3] = { v[C - 3], v[C - 2], v[C - 1] };
     prev_context<3>(last, xp, ctx, (int)(t & 1), t == sg.Tw);
     if (t == sg.Tw && sg.Tw > 0 && threadIdx.x == 0) { xp[0] = x[base - 3]; xp[1] = x[base - 2]; xp[2] = x[base - 1]; }
-    meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hs);
+    meter_chunk_l(v, xp, base, tile_base, n, pl, m, lds, hs);
   }
   meter_finish(m, lds, peaks + chan);
 }
@@ -52,8 +54,10 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
   float* y = out ? out + chan * n : nullptr;
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const Segment sg = make_segment(blockIdx.y, seg_tiles, warm, ntiles, pl.hop, pl.nhops);
-  MeterState m;
-  meter_init(m, pl, sg.Tw * kTile, &sg);
+  __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
+  MeterStateL m;
+  meter_init_l(m, pl, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
+  __syncthreads();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
       xp[0] = x[base - 3]; xp[1] = x[base - 2]; xp[2] = x[base - 1];
       if (gains) { xp[0] = f32r((double)xp[0] * G); xp[1] = f32r((double)xp[1] * G); xp[2] = f32r((double)xp[2] * G); }
     }
-    meter_chunk(v, xp, base, tile_base, n, pl, m, lds, hopsums + chan * hop_stride);
+    meter_chunk_l(v, xp, base, tile_base, n, pl, m, lds, hopsums + chan * hop_stride);
   }
   meter_finish(m, lds, peaks + chan);
 }

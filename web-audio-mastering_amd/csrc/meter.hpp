@@ -23,16 +23,6 @@ struct MeterPlan {
   int too_short;      // duration < 0.4 s -> lufs = fallback (lufs.js:23-26)
 };
 
-struct MeterState {            // carried across tiles, per channel
-  double P1[4], P2[4];         // lane powers of the two filters
-  double S1a, S1b, S2a, S2b;   // tile carries of the two filters
-  float y1m1, y1m2;            // (thread 0 only matters) - unused placeholders
-  double peak;                 // running true peak of this thread
-  int64_t hop_idx, hop_off;    // hop index / offset of this thread's chunk start
-  int64_t own_from;            // time segments: first sample whose peak this workgroup reports ...
-  int64_t hop_lo, hop_hi;      // ... and the hops [hop_lo, hop_hi) it accumulates (each hop has exactly one owner)
-};
-
 // A time segment of a (track, channel) walk: tiles [T0, T1), entered at tile Tw <= T0 with cold state (the warm-up
 // re-run).  A 100 ms hop belongs to the segment that holds its LAST sample, so the owner also sums the part of the
 // hop that lies in its warm-up tiles: every hop sum is accumulated by one workgroup, in tile order - deterministic,
@@ -50,19 +40,6 @@ __device__ __forceinline__ Segment make_segment(int64_t seg_idx, int64_t seg_til
   g.hop_hi = (g.T1 >= ntiles || hop <= 0) ? nhops : (g.T1 * kTile) / hop;
   if (g.hop_hi > nhops) g.hop_hi = nhops;
   return g;
-}
-
-__device__ __forceinline__ void meter_init(MeterState& m, const MeterPlan& pl, int64_t first_sample, const Segment* seg = nullptr) {
-  m.own_from = seg ? seg->own_from : 0;
-  m.hop_lo = seg ? seg->hop_lo : 0;
-  m.hop_hi = seg ? seg->hop_hi : pl.nhops;
-  biquad_lane_power(pl.shelf, lane_id(), m.P1);
-  biquad_lane_power(pl.hp, lane_id(), m.P2);
-  m.S1a = m.S1b = m.S2a = m.S2b = 0;
-  m.peak = 0;
-  const int64_t b = first_sample + (int64_t)threadIdx.x * C;
-  m.hop_idx = b / pl.hop;
-  m.hop_off = b - m.hop_idx * pl.hop;
 }
 
 // x[0..C) = this thread's samples (already rounded to f32 by the producing stage),
@@ -130,32 +107,17 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
   while (m.hop_off >= pl.hop) { m.hop_off -= pl.hop; m.hop_idx++; }
 }
 
-__device__ __forceinline__ void meter_chunk(const float x[C], const float xp[3], int64_t base, int64_t tile_base, int64_t n,
-                                            const MeterPlan& pl, MeterState& m, double* lds, double* hopsums) {
-  meter_peak_part(x, xp, base, n, m);
-  // ---- K-weighting
-  double v[C];
-#pragma unroll
-  for (int k = 0; k < C; k++) v[k] = (base + k < n) ? (double)x[k] : 0.0;
-  double s0, s1;
-  biquad_chunk(v, (base - 1 >= 0) ? (double)xp[2] : 0.0, (base - 2 >= 0) ? (double)xp[1] : 0.0, pl.shelf, m.P1, m.S1a, m.S1b, lds, s0, s1);
-#pragma unroll
-  for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
-  double t0, t1;
-  biquad_chunk(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2a, m.S2b, lds + 8, t0, t1);
-  meter_hop_part(v, base, tile_base, pl, m, lds, hopsums);
-}
-
-// The same with the two filters' lane powers ([64][4] doubles each) and tile carries ([2] each) in LDS, for kernels
-// that are short of registers (k_front): see biquad_chunk_lds.
-struct MeterStateL {
-  const double* P1; const double* P2; double* S1; double* S2;
-  double peak;
-  int64_t hop_idx, hop_off, own_from, hop_lo, hop_hi;
+// The two K-weighting filters' lane powers ([64][4] doubles each) and tile carries ([2] each) live in LDS: see biquad_chunk_lds.
+struct MeterStateL {            // carried across tiles, per channel
+  const double* P1; const double* P2; double* S1; double* S2;   // lane powers / tile carries of the two filters (LDS)
+  double peak;                 // running true peak of this thread
+  int64_t hop_idx, hop_off;    // hop index / offset of this thread's chunk start
+  int64_t own_from;            // time segments: first sample whose peak this workgroup reports ...
+  int64_t hop_lo, hop_hi;      // ... and the hops [hop_lo, hop_hi) it accumulates (each hop has exactly one owner)
 };
 __device__ __forceinline__ void meter_init_l(MeterStateL& m, const MeterPlan& pl, int64_t first_sample, const Segment& seg,
                                              double* P1, double* P2, double* S1, double* S2) {
-  if (wave_id() == 0) { biquad_lane_power(pl.shelf, lane_id(), P1 + 4 * lane_id()); biquad_lane_power(pl.hp, lane_id(), P2 + 4 * lane_id()); }
+  if (wave_id() == 0) { biquad_lane_power_table(pl.shelf, lane_id(), P1); biquad_lane_power_table(pl.hp, lane_id(), P2); }
   if (threadIdx.x < 2) { S1[threadIdx.x] = 0; S2[threadIdx.x] = 0; }
   m.P1 = P1; m.P2 = P2; m.S1 = S1; m.S2 = S2;
   m.peak = 0;

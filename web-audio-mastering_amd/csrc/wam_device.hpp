@@ -200,6 +200,14 @@ __device__ __forceinline__ void biquad_lane_power(const Biquad& q, int lane, dou
     if (lane & (1 << k)) { double t[4]; mat2_mul(q.Mp[k], P, t); P[0] = t[0]; P[1] = t[1]; P[2] = t[2]; P[3] = t[3]; }
   }
 }
+// The LDS table of a filter's lane powers is component-major, tab[64 c + lane] = (M^lane)[c]: a wavefront's 8-byte reads of
+// one component then touch consecutive banks (lane-major [lane][4] made them 8-way bank conflicts).
+__device__ __forceinline__ void biquad_lane_power_table(const Biquad& q, int lane, double* tab) {
+  double P[4];
+  biquad_lane_power(q, lane, P);
+#pragma unroll
+  for (int c = 0; c < 4; c++) tab[64 * c + lane] = P[c];
+}
 __device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane) {
   double p = 1;
 #pragma unroll
@@ -207,74 +215,16 @@ __device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane)
   return p;
 }
 
-// ---- second-order scan -------------------------------------------------------
-// In: (e0,e1) = chunk end state for zero start state.  Out: (e0,e1) = true start
-// state of this thread's chunk.  (S0,S1) = tile carry (start state of thread 0),
-// updated to the carry of the next tile.  lds: 8 doubles private to this call site.
-__device__ __forceinline__ void scan2(double& e0, double& e1, const Biquad& q, const double P[4],
-                                      double& S0, double& S1, double* lds) {
-  const int lane = lane_id(), wave = wave_id();
-  // (Hillis-Steele over the whole wavefront: the row-wise DPP form of biquad_chunk_lds needs the M^lane table in LDS for its
-  // broadcast steps, which this register variant does not have)
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const int d = 1 << k;
-    const double t0 = __shfl_up(e0, d), t1 = __shfl_up(e1, d);
-    if (lane >= d) { e0 += q.Mp[k][0] * t0 + q.Mp[k][1] * t1; e1 += q.Mp[k][2] * t0 + q.Mp[k][3] * t1; }
-  }
-  if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
-  const double x0 = dpp_d<0x138, 0xF>(0.0, e0), x1 = dpp_d<0x138, 0xF>(0.0, e1);
-  __syncthreads();
-  double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
-#pragma unroll
-  for (int w = 0; w < kWaves; w++) {
-    const double a0 = lds[2 * w], a1 = lds[2 * w + 1];
-    const double n0 = q.Mp[6][0] * w0 + q.Mp[6][1] * w1 + a0;
-    const double n1 = q.Mp[6][2] * w0 + q.Mp[6][3] * w1 + a1;
-    w0 = n0; w1 = n1;
-    if (w + 1 == wave) { my0 = w0; my1 = w1; }
-  }
-  S0 = w0; S1 = w1;
-  e0 = x0 + P[0] * my0 + P[1] * my1;
-  e1 = x1 + P[2] * my0 + P[3] * my1;
-}
-
-// One biquad stage over this thread's chunk, in place on x[] (double).
-// xm1/xm2 = the two inputs before the chunk.  s0/s1 returns the chunk's start
-// state (y[-1], y[-2]) = the previous thread's last two outputs in double: the
-// next cascaded stage takes its xm1/xm2 from them (after the f32 store rounding).
-// Three phases: feed-forward part in place; the recursion from zero state for the
-// chunk's end state only; scan; the recursion again from the true start state, which
-// reproduces the sequential DF-I evaluation order of utils.js:12-25 given that state.
-__device__ __forceinline__ void biquad_chunk(double x[C], double xm1, double xm2, const Biquad& q, const double P[4],
-                                             double& S0, double& S1, double* lds, double& s0, double& s1) {
-  const double b0 = q.b0, b1 = q.b1, b2 = q.b2, a1 = q.a1, a2 = q.a2;
-  double p1 = 0, p2 = 0, i1 = xm1, i2 = xm2;
-#pragma unroll
-  for (int n = 0; n < C; n++) {
-    const double xi = x[n];
-    const double w = b0 * xi + b1 * i1 + b2 * i2;
-    i2 = i1; i1 = xi;
-    x[n] = w;
-    const double y = w - a1 * p1 - a2 * p2;
-    p2 = p1; p1 = y;
-  }
-  s0 = p1; s1 = p2;
-  scan2(s0, s1, q, P, S0, S1, lds);
-  p1 = s0; p2 = s1;
-#pragma unroll
-  for (int n = 0; n < C; n++) {
-    const double y = x[n] - a1 * p1 - a2 * p2;
-    p2 = p1; p1 = y;
-    x[n] = y;
-  }
-}
-
-// ---- the same stage with its carried state in LDS -------------------------------------
-// Kernels that run many biquads per tile (the LR4 band splits) keep the lane powers M^lane ([64][4] doubles per
-// distinct filter) and the tile carries ([2] doubles per filter instance) in LDS instead of registers: 12 VGPRs per
-// instance that would otherwise be live across the whole tile loop.  Plds/Slds are written once at kernel start
-// (and Slds by thread 0 after each scan); a barrier separates every write from the next read.
+// ---- second-order sections ------------------------------------------------------
+// One biquad stage over this thread's chunk, in place on x[] (double).  xm1/xm2 = the two inputs before the chunk.
+// s0/s1 returns the chunk's start state (y[-1], y[-2]) = the previous thread's last two outputs in double: the next
+// cascaded stage takes its xm1/xm2 from them (after the f32 store rounding).  Three phases: feed-forward part in place
+// and the recursion from zero state for the chunk's end state only; a scan of the end states; the recursion again from
+// the true start state, which reproduces the sequential DF-I evaluation order of utils.js:12-25 given that state.
+// The lane powers M^lane ([4][64] doubles per distinct filter, M = the transition over one chunk) and the tile carries
+// ([2] doubles per filter instance) live in LDS, not registers: 12 VGPRs per instance that would otherwise be live
+// across the whole tile loop, and the table is what the scan's broadcast steps index.  Plds/Slds are written once at
+// kernel start (and Slds by thread 0 after each scan); a barrier separates every write from the next read.
 __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double xm2, const Biquad& q, const double* Plds, double* Slds,
                                                  double* lds, double& s0, double& s1) {
   const double b0 = q.b0, b1 = q.b1, b2 = q.b2, a1 = q.a1, a2 = q.a2;
@@ -298,12 +248,12 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
   {
     // ... then the aggregate of the row(s) below reaches a lane through M^(distance to that aggregate's lane): M^((lane & 15) + 1) for
     // the previous row's lane 15, M^(lane - 31) for lane 31 - both entries of the M^lane table
-    const double* Pa = Plds + 4 * ((lane & 15) + 1);
+    const double* Pa = Plds + ((lane & 15) + 1);
     const double ta0 = dpp_d<0x142, 0xA>(0.0, e0), ta1 = dpp_d<0x142, 0xA>(0.0, e1);
-    e0 += Pa[0] * ta0 + Pa[1] * ta1; e1 += Pa[2] * ta0 + Pa[3] * ta1;
-    const double* Pb = Plds + 4 * (lane >= 32 ? lane - 31 : 0);
+    e0 += Pa[0] * ta0 + Pa[64] * ta1; e1 += Pa[128] * ta0 + Pa[192] * ta1;
+    const double* Pb = Plds + (lane >= 32 ? lane - 31 : 0);
     const double tb0 = dpp_d<0x143, 0xC>(0.0, e0), tb1 = dpp_d<0x143, 0xC>(0.0, e1);
-    e0 += Pb[0] * tb0 + Pb[1] * tb1; e1 += Pb[2] * tb0 + Pb[3] * tb1;
+    e0 += Pb[0] * tb0 + Pb[64] * tb1; e1 += Pb[128] * tb0 + Pb[192] * tb1;
   }
   if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
   const double x0 = dpp_d<0x138, 0xF>(0.0, e0), x1 = dpp_d<0x138, 0xF>(0.0, e1);
@@ -318,9 +268,9 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
     if (w + 1 == wave) { my0 = w0; my1 = w1; }
   }
   if (threadIdx.x == 0) { Slds[0] = w0; Slds[1] = w1; }
-  const double* P = Plds + 4 * lane;
-  s0 = x0 + P[0] * my0 + P[1] * my1;
-  s1 = x1 + P[2] * my0 + P[3] * my1;
+  const double* P = Plds + lane;
+  s0 = x0 + P[0] * my0 + P[64] * my1;
+  s1 = x1 + P[128] * my0 + P[192] * my1;
   p1 = s0; p2 = s1;
 #pragma unroll
   for (int n = 0; n < C; n++) {
