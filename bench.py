@@ -246,7 +246,7 @@ def main():
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch), "avg_launch_ms": avg_ms,
                             "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
-                            "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,500 VALU "
+                            "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,600 VALU "
                                      "lane-instructions per 16 algorithmic bytes against a machine balance of ~5 per byte") if chain_like else
                                     ("two f64 K-weighting biquad scans + the 4-point peak interpolation per 4-byte sample: VALU-bound "
                                      "(DESIGN.md 5)" if wl == "meter" else "f32 butterflies in LDS; see DESIGN.md 5")}
