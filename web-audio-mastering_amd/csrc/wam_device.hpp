@@ -349,6 +349,22 @@ __device__ __forceinline__ void count_iters(int site, int iters) {
 __device__ __forceinline__ void count_iters(int, int) {}
 #endif
 
+// Workgroup vote: does `p` hold on any thread?  A ballot per wavefront, one flag per wavefront in LDS, ONE barrier
+// (HIP's __syncthreads_or makes three, an LDS atomic and ~60 instructions of lane arithmetic).  The flags are double-
+// buffered by `parity`, which the caller keeps and starts at 0: two votes on the same buffer then always have another
+// barrier between them (inside a solver consecutive votes alternate; between two solver calls lies at least a scan).
+__device__ __forceinline__ bool block_any(bool p, int& parity) {
+  __shared__ int flags[2][kWaves];
+  static_assert(kWaves == 4, "block_any reads the four flags as one int4");
+  const bool w = __ballot(p) != 0;
+  int* f = flags[parity];
+  parity ^= 1;
+  if (lane_id() == 0) f[wave_id()] = w;
+  __syncthreads();
+  const int4 v = *reinterpret_cast<const int4*>(f);
+  return (v.x | v.y | v.z | v.w) != 0;
+}
+
 // ---- piecewise-affine recurrences: policy iteration ---------------------------------
 // A recurrence e[n] = f_n(e[n-1]) whose step is piecewise affine (attack/release
 // followers, release smoothers with resets).  Each thread runs its chunk from a
@@ -366,7 +382,7 @@ __device__ __forceinline__ double solve_piecewise(Run run, double guess, double&
   const double S_in = S;
   double start = guess, prev = guess;
   unsigned pm = 0;
-  int it = 0;
+  int it = 0, vp = 0;
   for (; it < max_iter; it++) {
     double al, be;
     unsigned m;
@@ -374,15 +390,15 @@ __device__ __forceinline__ double solve_piecewise(Run run, double guess, double&
     // Same branches as in the previous pass = same maps = the scan would reproduce the start values this pass ran from:
     // they are the solution and S already holds the carry of that scan.  (The vote is also the barrier that lets lds be
     // rewritten.)
-    if (it > 0 && !__syncthreads_or((int)(m != pm))) break;
+    if (it > 0 && !block_any(m != pm, vp)) break;
     pm = m;
     double Sc = S_in;
     const double ns = scan_affine<CLAMP1>(al, be, Sc, lds);
     S = Sc;
-    if (EXACT_GUESS && it == 0 && !__syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(start))) { start = ns; break; }
+    if (EXACT_GUESS && it == 0 && !block_any(__double_as_longlong(ns) != __double_as_longlong(start), vp)) { start = ns; break; }
     // A comparison that is a tie to the last bit can flip with the ulp its own flip causes: a 2-cycle between two
     // start vectors that are both valid to rounding.  Detected from the 4th pass on (one more vote), then ended.
-    if (it >= 3 && !__syncthreads_or(__double_as_longlong(ns) != __double_as_longlong(prev))) { start = ns; break; }
+    if (it >= 3 && !block_any(__double_as_longlong(ns) != __double_as_longlong(prev), vp)) { start = ns; break; }
     prev = start;
     start = ns;
   }
@@ -469,7 +485,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
 #endif
   double p1 = s1, p2 = s2;
   unsigned pm = 0;                                                // branch pattern of the previous pass, 2 bits per sample
-  int it = 0;
+  int it = 0, vp = 0;
   for (; it < 260; it++) {
     double al1 = 1, be1 = 0, al2 = 1, be2 = 0;
     unsigned m = 0;
@@ -485,7 +501,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
     }
     // Same pattern as in the previous pass = same maps = the scan would reproduce the start values this pass ran from:
     // they are the solution, and S1 / S2 already hold the carries of that scan.  (Also the barrier that lets lds be rewritten.)
-    if (it > 0 && !__syncthreads_or((int)(m != pm))) break;
+    if (it > 0 && !block_any(m != pm, vp)) break;
     pm = m;
 #define WAM_PAIR_STEP(CTRL, RM) { affine_step<CTRL, RM>(al1, be1); affine_step<CTRL, RM>(al2, be2); }
     WAM_PAIR_STEP(0x111, 0xF) WAM_PAIR_STEP(0x112, 0xF) WAM_PAIR_STEP(0x114, 0xF) WAM_PAIR_STEP(0x118, 0xF)
@@ -505,7 +521,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
     S1 = w1; S2 = w2;
     // A comparison that is a tie to the last bit can flip with the ulp its own flip causes: a 2-cycle between two start
     // vectors that are both valid to rounding.  Detected from the 4th pass on (one vote), then ended.
-    if (it >= 3 && !__syncthreads_or((int)(__double_as_longlong(n1) != __double_as_longlong(p1)) | (int)(__double_as_longlong(n2) != __double_as_longlong(p2)))) {
+    if (it >= 3 && !block_any(__double_as_longlong(n1) != __double_as_longlong(p1) || __double_as_longlong(n2) != __double_as_longlong(p2), vp)) {
       s1 = n1; s2 = n2; break;
     }
     p1 = s1; p2 = s2;
