@@ -651,7 +651,7 @@ constexpr int kCross = 448;                      // crossing list capacity per f
 
 // DPP moves for the wavefront scans (no LDS round trip, unlike ds_bpermute): lanes without a source read 0, the identity of
 // the scans below.  row_shr:n = 0x110 + n; row_bcast:15 = 0x142 (lane 15 of every row to the next row, row mask 0xA);
-// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xC).
+// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xC); wave_shr:1 = 0x138.
 template <int CTRL, int RM> __device__ __forceinline__ int dppm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, false); }
 template <int CTRL, int RM> __device__ __forceinline__ float dppm(float v) { return __int_as_float(dppm<CTRL, RM>(__float_as_int(v))); }
 template <int CTRL, int RM> __device__ __forceinline__ double dppm(double v) {
@@ -673,8 +673,7 @@ __device__ __forceinline__ void seg_scan16(T val[16], unsigned starts, int lane)
   int fl = starts != 0;
   seg_step<0x111, 0xF>(v, fl); seg_step<0x112, 0xF>(v, fl); seg_step<0x114, 0xF>(v, fl); seg_step<0x118, 0xF>(v, fl);
   seg_step<0x142, 0xA>(v, fl); seg_step<0x143, 0xC>(v, fl);
-  T carry = __shfl_up(v, 1);
-  if (lane == 0) carry = 0;
+  const T carry = dppm<0x138, 0xF>(v);                             // wave_shr:1, lane 0 reads 0
   const int first = starts ? __builtin_ctz(starts) : 16;
 #pragma unroll
   for (int i = 0; i < 16; i++) if (i < first) val[i] += carry;
