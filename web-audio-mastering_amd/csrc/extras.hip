@@ -25,8 +25,8 @@ __global__ __launch_bounds__(256) void k_dc_partial(const float* __restrict__ in
   int64_t en = st + per; if (en > n) en = n;
   double s = 0;
   for (int64_t i = st + threadIdx.x; i < en; i += 256) s += (double)x[i];
-  s = wave_sum_ordered(s);
-  if (lane_id() == 0) red[wave_id()] = s;
+  s = wave_sum_lane63(s);
+  if (lane_id() == 63) red[wave_id()] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[chan * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }

@@ -89,8 +89,8 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
       if (h > h_last) break;
       double c = 0;
       if (h == m.hop_idx) c = sA; else if (h == m.hop_idx + 1) c = sB;
-      c = wave_sum_ordered(c);
-      if (lane_id() == 0) part[wave_id() * 4 + j] = c;
+      c = wave_sum_lane63(c);
+      if (lane_id() == 63) part[wave_id() * 4 + j] = c;
     }
     __syncthreads();
     if (threadIdx.x < 4) {

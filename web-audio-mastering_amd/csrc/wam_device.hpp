@@ -159,12 +159,6 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d));
   return v;
 }
-__device__ __forceinline__ double wave_sum_ordered(double v) {   // fixed tree: deterministic
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
 // DPP moves for the wavefront scans: no LDS round trip (ds_bpermute, which __shfl_up compiles to, takes one per 32 bits) and
 // no lane arithmetic; a lane without a source keeps `old`, which the callers set to the identity of their scan.
 // row_shr:n = 0x110 + n (within rows of 16 lanes); row_bcast:15 = 0x142 with row mask 0xA (lane 15 of rows 0 / 2 to rows
@@ -185,6 +179,13 @@ template <int CTRL, int RM> __device__ __forceinline__ void affine_step(double& 
 __device__ __forceinline__ void wave_scan_affine(double& al, double& be) {
   affine_step<0x111, 0xF>(al, be); affine_step<0x112, 0xF>(al, be); affine_step<0x114, 0xF>(al, be); affine_step<0x118, 0xF>(al, be);
   affine_step<0x142, 0xA>(al, be); affine_step<0x143, 0xC>(al, be);
+}
+
+// Sum over the wavefront in a fixed order (deterministic); the total is valid in LANE 63 only.
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_d<0x111, 0xF>(0.0, v); v += dpp_d<0x112, 0xF>(0.0, v); v += dpp_d<0x114, 0xF>(0.0, v); v += dpp_d<0x118, 0xF>(0.0, v);
+  v += dpp_d<0x142, 0xA>(0.0, v); v += dpp_d<0x143, 0xC>(0.0, v);
+  return v;
 }
 
 __device__ __forceinline__ void mat2_mul(const double a[4], const double b[4], double o[4]) {
