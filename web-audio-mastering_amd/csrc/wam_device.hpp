@@ -438,6 +438,9 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
   const int lane = lane_id(), wave = wave_id();
   const double S1_in = S1, S2_in = S2;
   double s1 = S1, s2 = S2;
+#ifndef WAM_PRESOLVE_PASSES
+#define WAM_PRESOLVE_PASSES 2
+#endif
 #ifndef WAM_NO_F32_PRESOLVE
   // The first passes only have to get the branch pattern roughly right: they run in packed single precision (both
   // followers in one v_pk_* instruction, half the shuffles) and need no convergence vote.  The double-precision loop below
@@ -448,7 +451,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
     const v2f A = { (float)A1, (float)A2 }, R = { (float)R1, (float)R2 }, Sin = { (float)S1, (float)S2 };
     v2f st = Sin;
 #pragma unroll 1
-    for (int pre = 0; pre < 2; pre++) {
+    for (int pre = 0; pre < WAM_PRESOLVE_PASSES; pre++) {
       v2f al = { 1.0f, 1.0f }, be = { 0.0f, 0.0f };
 #pragma unroll
       for (int n = 0; n < C; n++) {
@@ -465,7 +468,7 @@ __device__ __forceinline__ void follower_solve2(const T a[C], double A1, double 
         tb.x = dpp_f<CTRL, RM>(0.0f, be.x); tb.y = dpp_f<CTRL, RM>(0.0f, be.y); be = al * tb + be; al = al * ta; }
       WAM_PRE_STEP(0x111, 0xF) WAM_PRE_STEP(0x112, 0xF) WAM_PRE_STEP(0x114, 0xF) WAM_PRE_STEP(0x118, 0xF)
       WAM_PRE_STEP(0x142, 0xA) WAM_PRE_STEP(0x143, 0xC)
-      float* ldsf = (float*)lds + 16 * pre;                       // the slot's 16 doubles = two regions of 16 floats, one per pass
+      float* ldsf = (float*)lds + 16 * (pre & 1);                       // the slot's 16 doubles = two regions of 16 floats, one per pass
       if (lane == 63) { ldsf[4 * wave] = al.x; ldsf[4 * wave + 1] = al.y; ldsf[4 * wave + 2] = be.x; ldsf[4 * wave + 3] = be.y; }
       v2f xa, xb;
       xa.x = dpp_f<0x138, 0xF>(1.0f, al.x); xa.y = dpp_f<0x138, 0xF>(1.0f, al.y);
