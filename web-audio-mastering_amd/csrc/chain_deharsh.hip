@@ -719,7 +719,7 @@ __device__ __forceinline__ bool band_energies_scan(const float* mags, BandScanLd
   bool bad = false;
 #pragma unroll
   for (int i = 0; i < 16; i++) { e[i] = (int)(__float_as_uint(D[i]) >> 23) & 0xff; bad |= e[i] < 24 || e[i] > 250; }
-  int eprev = __shfl_up(e[15], 1);
+  int eprev = dppm<0x138, 0xF>(e[15]);                            // the lane below's last bin (lane 0: a band start anyway)
   unsigned xm = L.bsm;
 #pragma unroll
   for (int i = 0; i < 16; i++) { if (e[i] != eprev) xm |= 1u << i; eprev = e[i]; }
@@ -747,7 +747,7 @@ __device__ __forceinline__ bool band_energies_scan(const float* mags, BandScanLd
   if (lane < 8) W.lstart[lane] = total;
   wave_sync();
   {                                                               // 3. the crossing list
-    int rp = __shfl_up(r[15], 1), ep = __shfl_up(e[15], 1), pc = base;
+    int rp = dppm<0x138, 0xF>(r[15]), ep = dppm<0x138, 0xF>(e[15]), pc = base;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const bool cross = (xm >> i) & 1;

@@ -148,49 +148,35 @@ __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, co
 template <class Consume>
 __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float xm2, SplitState& st, const Biquad& lp1, const Biquad& hp1,
                                             const Biquad& lp2, const Biquad& hp2, LdsSlots& slots, Consume consume) {
-  double d[C], s0, s1, t0, t1;
+  // The two filters of a split level read the same input, so each cascade stage of the pair runs under one barrier with
+  // its two recursions interleaved (biquad_pair_lds): low = lp1(lp1(x)) with midHigh = hp1(hp1(x)), then mid =
+  // lp2(lp2(mh)) with high = hp2(hp2(mh)).  The band that waits for its turn is kept as f32 (16 registers).
+  double da[C], db[C], a0, a1, b0, b1, c0, c1, e0, e1;
   float band[C];
-  // low = lp1(lp1(x))
 #pragma unroll
-  for (int k = 0; k < C; k++) d[k] = v[k];
-  biquad_chunk_lds(d, xm1, xm2, lp1, &st.P[0][0][0], st.S[0], slots.next(), s0, s1);
+  for (int k = 0; k < C; k++) { da[k] = v[k]; db[k] = v[k]; }
+  biquad_pair_lds(da, xm1, xm2, lp1, &st.P[0][0][0], st.S[0], db, xm1, xm2, hp1, &st.P[1][0][0], st.S[2], slots.next(), a0, a1, b0, b1);
 #pragma unroll
-  for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), lp1, &st.P[0][0][0], st.S[1], slots.next(), t0, t1);
-#pragma unroll
-  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
-  consume(0, band);
-  // midHigh = hp1(hp1(x))
-#pragma unroll
-  for (int k = 0; k < C; k++) d[k] = v[k];
-  biquad_chunk_lds(d, xm1, xm2, hp1, &st.P[1][0][0], st.S[2], slots.next(), s0, s1);
-#pragma unroll
-  for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), hp1, &st.P[1][0][0], st.S[3], slots.next(), t0, t1);
+  for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
+  biquad_pair_lds(da, (double)f32r(a0), (double)f32r(a1), lp1, &st.P[0][0][0], st.S[1],
+                  db, (double)f32r(b0), (double)f32r(b1), hp1, &st.P[1][0][0], st.S[3], slots.next(), c0, c1, e0, e1);
   float mh[C];
 #pragma unroll
-  for (int k = 0; k < C; k++) mh[k] = f32r(d[k]);
-  const double mh1 = (double)f32r(t0), mh2 = (double)f32r(t1);
-  // mid = lp2(lp2(mh))
+  for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); mh[k] = f32r(db[k]); }
+  const double mh1 = (double)f32r(e0), mh2 = (double)f32r(e1);
+  consume(0, band);
 #pragma unroll
-  for (int k = 0; k < C; k++) d[k] = mh[k];
-  biquad_chunk_lds(d, mh1, mh2, lp2, &st.P[2][0][0], st.S[4], slots.next(), s0, s1);
+  for (int k = 0; k < C; k++) { da[k] = mh[k]; db[k] = mh[k]; }
+  biquad_pair_lds(da, mh1, mh2, lp2, &st.P[2][0][0], st.S[4], db, mh1, mh2, hp2, &st.P[3][0][0], st.S[6], slots.next(), a0, a1, b0, b1);
 #pragma unroll
-  for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), lp2, &st.P[2][0][0], st.S[5], slots.next(), t0, t1);
+  for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
+  biquad_pair_lds(da, (double)f32r(a0), (double)f32r(a1), lp2, &st.P[2][0][0], st.S[5],
+                  db, (double)f32r(b0), (double)f32r(b1), hp2, &st.P[3][0][0], st.S[7], slots.next(), c0, c1, e0, e1);
+  float high[C];
 #pragma unroll
-  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
+  for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); high[k] = f32r(db[k]); }
   consume(1, band);
-  // high = hp2(hp2(mh))
-#pragma unroll
-  for (int k = 0; k < C; k++) d[k] = mh[k];
-  biquad_chunk_lds(d, mh1, mh2, hp2, &st.P[3][0][0], st.S[6], slots.next(), s0, s1);
-#pragma unroll
-  for (int k = 0; k < C; k++) d[k] = (double)f32r(d[k]);
-  biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), hp2, &st.P[3][0][0], st.S[7], slots.next(), t0, t1);
-#pragma unroll
-  for (int k = 0; k < C; k++) band[k] = f32r(d[k]);
-  consume(2, band);
+  consume(2, high);
 }
 
 // WARM / PUNCH are compile-time so that each instantiation carries only its own filter state: the two stages run as

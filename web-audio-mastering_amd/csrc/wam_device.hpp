@@ -226,8 +226,10 @@ __device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane)
 // ([2] doubles per filter instance) live in LDS, not registers: 12 VGPRs per instance that would otherwise be live
 // across the whole tile loop, and the table is what the scan's broadcast steps index.  Plds/Slds are written once at
 // kernel start (and Slds by thread 0 after each scan); a barrier separates every write from the next read.
-__device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double xm2, const Biquad& q, const double* Plds, double* Slds,
-                                                 double* lds, double& s0, double& s1) {
+struct BiquadMid { double x0, x1, S0, S1; };        // between the two halves: exclusive in-wave state, the tile carry
+// First half: feed-forward part in place, zero-state recursion, in-wave scan; lane 63 publishes the wave aggregate in ldsw[0..1].
+__device__ __forceinline__ void biquad_pre(double x[C], double xm1, double xm2, const Biquad& q, const double* Plds, const double* Slds,
+                                           double* ldsw, BiquadMid& m) {
   const double b0 = q.b0, b1 = q.b1, b2 = q.b2, a1 = q.a1, a2 = q.a2;
   double p1 = 0, p2 = 0, i1 = xm1, i2 = xm2;
 #pragma unroll
@@ -240,8 +242,8 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
     p2 = p1; p1 = y;
   }
   double e0 = p1, e1 = p2;
-  const int lane = lane_id(), wave = wave_id();
-  const double S0 = Slds[0], S1 = Slds[1];           // read before the barrier below; rewritten after it
+  const int lane = lane_id();
+  m.S0 = Slds[0]; m.S1 = Slds[1];                    // read before the caller's barrier; rewritten after it
   // weighted prefix sum of the end states: inside the rows of 16 lanes by DPP row shifts (uniform powers M^1, M^2, M^4, M^8) ...
 #define WAM_SCAN2_ROW(K, CTRL) { const double t0 = dpp_d<CTRL, 0xF>(0.0, e0), t1 = dpp_d<CTRL, 0xF>(0.0, e1); \
     e0 += q.Mp[K][0] * t0 + q.Mp[K][1] * t1; e1 += q.Mp[K][2] * t0 + q.Mp[K][3] * t1; }
@@ -256,13 +258,19 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
     const double tb0 = dpp_d<0x143, 0xC>(0.0, e0), tb1 = dpp_d<0x143, 0xC>(0.0, e1);
     e0 += Pb[0] * tb0 + Pb[64] * tb1; e1 += Pb[128] * tb0 + Pb[192] * tb1;
   }
-  if (lane == 63) { lds[2 * wave] = e0; lds[2 * wave + 1] = e1; }
-  const double x0 = dpp_d<0x138, 0xF>(0.0, e0), x1 = dpp_d<0x138, 0xF>(0.0, e1);
-  __syncthreads();
-  double w0 = S0, w1 = S1, my0 = S0, my1 = S1;
+  if (lane == 63) { ldsw[0] = e0; ldsw[1] = e1; }
+  m.x0 = dpp_d<0x138, 0xF>(0.0, e0); m.x1 = dpp_d<0x138, 0xF>(0.0, e1);
+}
+// Second half (after a workgroup barrier): the four wave aggregates lds4[2 w .. 2 w + 1] -> this thread's start state, the
+// recursion again from it; thread 0 stores the next tile's carry.
+__device__ __forceinline__ void biquad_post(double x[C], const Biquad& q, const double* Plds, double* Slds, const double* lds4,
+                                            const BiquadMid& m, double& s0, double& s1) {
+  const double a1 = q.a1, a2 = q.a2;
+  const int lane = lane_id(), wave = wave_id();
+  double w0 = m.S0, w1 = m.S1, my0 = m.S0, my1 = m.S1;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) {
-    const double c0 = lds[2 * w], c1 = lds[2 * w + 1];
+    const double c0 = lds4[2 * w], c1 = lds4[2 * w + 1];
     const double n0 = q.Mp[6][0] * w0 + q.Mp[6][1] * w1 + c0;
     const double n1 = q.Mp[6][2] * w0 + q.Mp[6][3] * w1 + c1;
     w0 = n0; w1 = n1;
@@ -270,15 +278,34 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
   }
   if (threadIdx.x == 0) { Slds[0] = w0; Slds[1] = w1; }
   const double* P = Plds + lane;
-  s0 = x0 + P[0] * my0 + P[64] * my1;
-  s1 = x1 + P[128] * my0 + P[192] * my1;
-  p1 = s0; p2 = s1;
+  s0 = m.x0 + P[0] * my0 + P[64] * my1;
+  s1 = m.x1 + P[128] * my0 + P[192] * my1;
+  double p1 = s0, p2 = s1;
 #pragma unroll
   for (int n = 0; n < C; n++) {
     const double y = x[n] - a1 * p1 - a2 * p2;
     p2 = p1; p1 = y;
     x[n] = y;
   }
+}
+__device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double xm2, const Biquad& q, const double* Plds, double* Slds,
+                                                 double* lds, double& s0, double& s1) {
+  BiquadMid m;
+  biquad_pre(x, xm1, xm2, q, Plds, Slds, lds + 2 * wave_id(), m);
+  __syncthreads();
+  biquad_post(x, q, Plds, Slds, lds, m, s0, s1);
+}
+// Two independent stages (two filters on one input, or one filter on two channels) under ONE barrier; their dependent
+// recursions interleave.  lds: the call site's 16 doubles.
+__device__ __forceinline__ void biquad_pair_lds(double xa[C], double xam1, double xam2, const Biquad& qa, const double* Pa, double* Sa,
+                                                double xb[C], double xbm1, double xbm2, const Biquad& qb, const double* Pb, double* Sb,
+                                                double* lds, double& sa0, double& sa1, double& sb0, double& sb1) {
+  BiquadMid ma, mb;
+  biquad_pre(xa, xam1, xam2, qa, Pa, Sa, lds + 2 * wave_id(), ma);
+  biquad_pre(xb, xbm1, xbm2, qb, Pb, Sb, lds + 8 + 2 * wave_id(), mb);
+  __syncthreads();
+  biquad_post(xa, qa, Pa, Sa, lds, ma, sa0, sa1);
+  biquad_post(xb, qb, Pb, Sb, lds + 8, mb, sb0, sb1);
 }
 
 // ---- first-order scan ----------------------------------------------------------
