@@ -57,6 +57,65 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     const int par = (int)(t & 1);
     float w[NCH][C];
+    if constexpr (NCH == 2) {
+      // Both channels in lock-step: every cascade stage is a fused pair (one barrier for the two channels, their
+      // recursions interleaved) - the same filters, separate tile carries and context sites.
+      float va[C], vb[C];
+      load_chunk(x[0], n, base, va);
+      load_chunk(x[1], n, base, vb);
+      if (pre_gain != 1.0) {
+#pragma unroll
+        for (int k = 0; k < C; k++) { va[k] = f32r((double)va[k] * pre_gain); vb[k] = f32r((double)vb[k] * pre_gain); }
+      }
+      double da[C], db[C];
+#pragma unroll
+      for (int k = 0; k < C; k++) { da[k] = va[k]; db[k] = vb[k]; }
+      double na1 = 0, na2 = 0, nb1 = 0, nb2 = 0;   // the two inputs before the chunk, for the next biquad's FIR part
+      bool have_nb = false;
+      if (P.do_hpf) {
+        const float la[2] = { va[C - 2], va[C - 1] }, lb[2] = { vb[C - 2], vb[C - 1] };
+        float pa[2], pb[2];
+        prev_ctx2<2>(la, pa, ctx[0], lb, pb, ctx[9], par, first);
+        double a0, a1, b0, b1;
+        biquad_pair_lds(da, pa[1], pa[0], P.hpf30, &Pl[kFHpf][0][0], Sl[0], db, pb[1], pb[0], P.hpf30, &Pl[kFHpf][0][0], Sl[9], slots.next(), a0, a1, b0, b1);
+#pragma unroll
+        for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
+        na1 = (double)f32r(a0); na2 = (double)f32r(a1); nb1 = (double)f32r(b0); nb2 = (double)f32r(b1); have_nb = true;
+      }
+      if (P.do_lpf) {
+        // applyOnePoleLP (final-filters.js:68-78): y starts at data[0]
+        if (t == 0) {
+          if (threadIdx.x == 0) { bc[0] = f32r(da[0]); bc[1] = f32r(db[0]); }
+          __syncthreads();
+          const float f0 = bc[0], f1 = bc[1];
+          Slpf[0] = (f0 == f0) ? (double)f0 : 0.0; Slpf[1] = (f1 == f1) ? (double)f1 : 0.0;
+        }
+        double ua[C], ub[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) { ua[k] = P.lpf_alpha * da[k]; ub[k] = P.lpf_alpha * db[k]; }
+        onepole_pair(ua, ub, P.lpf18, Plpf, Slpf[0], Slpf[1], slots.next());
+#pragma unroll
+        for (int k = 0; k < C; k++) { da[k] = (double)f32r(ua[k]); db[k] = (double)f32r(ub[k]); }
+        have_nb = false;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        if (b >= P.n_eq) break;
+        if (!have_nb) {
+          const float la[2] = { f32r(da[C - 2]), f32r(da[C - 1]) }, lb[2] = { f32r(db[C - 2]), f32r(db[C - 1]) };
+          float pa[2], pb[2];
+          prev_ctx2<2>(la, pa, ctx[1 + b], lb, pb, ctx[9 + 1 + b], par, first);
+          na1 = pa[1]; na2 = pa[0]; nb1 = pb[1]; nb2 = pb[0];
+        }
+        double a0, a1, b0, b1;
+        biquad_pair_lds(da, na1, na2, P.eq[b], &Pl[kFEq0 + b][0][0], Sl[1 + b], db, nb1, nb2, P.eq[b], &Pl[kFEq0 + b][0][0], Sl[9 + 1 + b], slots.next(), a0, a1, b0, b1);
+#pragma unroll
+        for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
+        na1 = (double)f32r(a0); na2 = (double)f32r(a1); nb1 = (double)f32r(b0); nb2 = (double)f32r(b1); have_nb = true;
+      }
+#pragma unroll
+      for (int k = 0; k < C; k++) { w[0][k] = f32r(da[k]); w[NCH - 1][k] = f32r(db[k]); }
+    } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       float v[C];
@@ -115,6 +174,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
 #pragma unroll
       for (int k = 0; k < C; k++) w[c][k] = f32r(d[k]);
     }
+    }
 
     if (P.do_glue) {
       // linked side-chain (dsp-worker.js:1287-1293), follower :1304-1312, gain :1318-1324
@@ -169,6 +229,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
       }
     }
 
+    if constexpr (NCH == 2) {
+      if (t >= sg.T0) { store_chunk(y[0], n, base, w[0]); store_chunk(y[1], n, base, w[1]); }
+      if (do_meter) {
+        const float la[3] = { w[0][C - 3], w[0][C - 2], w[0][C - 1] }, lb[3] = { w[1][C - 3], w[1][C - 2], w[1][C - 1] };
+        float xa[3], xb[3];
+        prev_ctx2<3>(la, xa, ctx[8], lb, xb, ctx[9 + 8], par, first);
+        meter_chunk_l2(w[0], xa, w[1], xb, base, tile_base, n, *reload_each_tile(mp), ms[0], ms[NCH - 1], lds_meter[0], lds_meter[NCH - 1],
+                       hopsums + (trk * NCH) * hop_stride, hopsums + (trk * NCH + 1) * hop_stride);
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       if (t >= sg.T0) store_chunk(y[c], n, base, w[c]);
@@ -178,6 +248,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         prev_ctx<3>(last, xp, ctx[c * 9 + 8], par, first);
         meter_chunk_l(w[c], xp, base, tile_base, n, *reload_each_tile(mp), ms[c], lds_meter[c], hopsums + (trk * NCH + c) * hop_stride);
       }
+    }
     }
   }
   if (do_meter) for (int c = 0; c < NCH; c++) meter_finish(ms[c], lds_meter[c], peaks + trk * NCH + c);

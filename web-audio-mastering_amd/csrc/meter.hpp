@@ -141,6 +141,27 @@ __device__ __forceinline__ void meter_chunk_l(const float x[C], const float xp[3
   meter_hop_part(v, base, tile_base, pl, m, lds, hopsums);
 }
 
+// Two channels of one track in lock-step: the K-weighting stages as fused pairs (one barrier per stage for both channels).
+__device__ __forceinline__ void meter_chunk_l2(const float xa[C], const float xpa[3], const float xb[C], const float xpb[3],
+                                               int64_t base, int64_t tile_base, int64_t n, const MeterPlan& pl,
+                                               MeterStateL& ma, MeterStateL& mb, double* ldsa, double* ldsb, double* hsa, double* hsb) {
+  meter_peak_part(xa, xpa, base, n, ma);
+  meter_peak_part(xb, xpb, base, n, mb);
+  double va[C], vb[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) { const bool in = base + k < n; va[k] = in ? (double)xa[k] : 0.0; vb[k] = in ? (double)xb[k] : 0.0; }
+  double a0, a1, b0, b1, c0, c1, d0, d1;
+  const bool h1 = base - 1 >= 0, h2 = base - 2 >= 0;
+  biquad_pair_lds(va, h1 ? (double)xpa[2] : 0.0, h2 ? (double)xpa[1] : 0.0, pl.shelf, ma.P1, ma.S1,
+                  vb, h1 ? (double)xpb[2] : 0.0, h2 ? (double)xpb[1] : 0.0, pl.shelf, mb.P1, mb.S1, ldsa, a0, a1, b0, b1);
+#pragma unroll
+  for (int k = 0; k < C; k++) { va[k] = (double)f32r(va[k]); vb[k] = (double)f32r(vb[k]); }
+  biquad_pair_lds(va, (double)f32r(a0), (double)f32r(a1), pl.hp, ma.P2, ma.S2,
+                  vb, (double)f32r(b0), (double)f32r(b1), pl.hp, mb.P2, mb.S2, ldsb, c0, c1, d0, d1);
+  meter_hop_part(va, base, tile_base, pl, ma, ldsa, hsa);
+  meter_hop_part(vb, base, tile_base, pl, mb, ldsb, hsb);
+}
+
 // Workgroup-wide final peak, max-ed into peaks[0] (zeroed before the launch; segments of one channel share it).
 // Non-negative doubles order like their bit patterns.
 template <class St>

@@ -340,6 +340,31 @@ __device__ __forceinline__ void onepole_chunk(double u[C], const OnePole& q, dou
   for (int n = 0; n < C; n++) { p = c * p + u[n]; u[n] = p; }
 }
 
+// Two independent one-pole sections (one filter, two channels) under one barrier.  lds: 8 doubles.
+__device__ __forceinline__ void onepole_pair(double ua[C], double ub[C], const OnePole& q, double Pl, double& Sa, double& Sb, double* lds) {
+  const double c = q.c;
+  const int lane = lane_id(), wave = wave_id();
+  double pa = 0, pb = 0;
+#pragma unroll
+  for (int n = 0; n < C; n++) { pa = c * pa + ua[n]; pb = c * pb + ub[n]; }
+  double ala = q.Mp[0], alb = q.Mp[0];
+  wave_scan_affine(ala, pa);
+  wave_scan_affine(alb, pb);
+  if (lane == 63) { lds[wave] = pa; lds[4 + wave] = pb; }
+  const double xa = dpp_d<0x138, 0xF>(0.0, pa), xb = dpp_d<0x138, 0xF>(0.0, pb);
+  __syncthreads();
+  double wa = Sa, wb = Sb, mya = Sa, myb = Sb;
+#pragma unroll
+  for (int k = 0; k < kWaves; k++) {
+    wa = q.Mp[6] * wa + lds[k]; wb = q.Mp[6] * wb + lds[4 + k];
+    if (k + 1 == wave) { mya = wa; myb = wb; }
+  }
+  Sa = wa; Sb = wb;
+  pa = xa + Pl * mya; pb = xb + Pl * myb;
+#pragma unroll
+  for (int n = 0; n < C; n++) { pa = c * pa + ua[n]; ua[n] = pa; pb = c * pb + ub[n]; ub[n] = pb; }
+}
+
 // ---- affine scan (per-thread coefficients), used by the follower policy iteration ----
 // Each thread's chunk maps start value e to (al * e + be).  Returns this thread's
 // start value given the tile carry S; S advances to the next tile's carry.
@@ -669,6 +694,30 @@ __device__ __forceinline__ void prev_ctx(const float last[K], float prev[K], flo
     } else {
 #pragma unroll
       for (int k = 0; k < K; k++) prev[k] = cur[(wave - 1) * K + k];
+    }
+  }
+}
+// Two sites (two channels) under one barrier.
+template <int K>
+__device__ __forceinline__ void prev_ctx2(const float lastA[K], float prevA[K], float* siteA, const float lastB[K], float prevB[K], float* siteB,
+                                          int parity, bool first_tile) {
+  const int lane = lane_id(), wave = wave_id();
+  float* curA = siteA + parity * kWaves * K; const float* oldA = siteA + (parity ^ 1) * kWaves * K;
+  float* curB = siteB + parity * kWaves * K; const float* oldB = siteB + (parity ^ 1) * kWaves * K;
+#pragma unroll
+  for (int k = 0; k < K; k++) { prevA[k] = dpp_f<0x138, 0xF>(0.0f, lastA[k]); prevB[k] = dpp_f<0x138, 0xF>(0.0f, lastB[k]); }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < K; k++) { curA[wave * K + k] = lastA[k]; curB[wave * K + k] = lastB[k]; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) { prevA[k] = first_tile ? 0.0f : oldA[(kWaves - 1) * K + k]; prevB[k] = first_tile ? 0.0f : oldB[(kWaves - 1) * K + k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) { prevA[k] = curA[(wave - 1) * K + k]; prevB[k] = curB[(wave - 1) * K + k]; }
     }
   }
 }
