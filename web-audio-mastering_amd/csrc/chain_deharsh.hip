@@ -540,14 +540,6 @@ __device__ __forceinline__ void dft16_d(dcx v[16]) {
     for (int kb = 0; kb < 4; kb++) v[ka + 4 * kb] = b[kb];
   }
 }
-__device__ __forceinline__ double quad_xor2_d(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_xor1_d(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
 // tables (double): twl[64 (k - 1) + lane] = W1024^(lane k), twq[16 q + k] = W64^(q k), twB[k] = W2048^k.  The kernels keep twq and
 // twl's k = 1..8 in LDS (what it has room for beside the exchange buffers) and read twB from global memory.
 struct WaveTwD { const dcx* l; const dcx* q; };
@@ -596,14 +588,28 @@ __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD
   dft16_d<INV>(v);
 #pragma unroll
   for (int k = 1; k < 16; k++) { const dcx w = T.q[16 * q + k]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
-  const double sg1 = (q & 2) ? -1.0 : 1.0, sg2 = (q & 1) ? -1.0 : 1.0;
+  // Last stage: the radix-4 over the four lanes of a quad.  In double a DPP exchange costs two moves per 32 bits moved (8 per
+  // complex value and stage: 256 moves + selects per transform), so the quad is transposed through LDS instead: lane
+  // (a, q) = (lane >> 2, lane & 3) stores its sixteen k2-values into row a, slot 4 k2 + ((q + (k2 >> 2)) & 3) - the skew
+  // makes both directions conflict-free - and reads back, for its four k2 = 4 q + i, all four q-values; the butterflies
+  // then run in registers.  On return v[i + 4 k3] = Z[a + 64 q + 16 i + 256 k3] = Z[wave_out_index_d(i + 4 k3)].
+  dcx* tr = ex + (lane >> 2) * kExRow;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    dcx a{ fma(sg1, v[k].x, quad_xor2_d(v[k].x)), fma(sg1, v[k].y, quad_xor2_d(v[k].y)) };
-    if (q == 3) a = INV ? dcx{ -a.y, a.x } : dcx{ a.y, -a.x };
-    v[k] = dcx{ fma(sg2, a.x, quad_xor1_d(a.x)), fma(sg2, a.y, quad_xor1_d(a.y)) };
+  for (int k = 0; k < 16; k++) tr[4 * k + ((q + (k >> 2)) & 3)] = v[k];
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    dcx x[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) x[qq] = tr[4 * (4 * q + i) + ((qq + q) & 3)];
+    r4_butterfly_d<INV>(x);
+#pragma unroll
+    for (int k3 = 0; k3 < 4; k3++) v[i + 4 * k3] = x[k3];
   }
 }
+// slot of this lane's j-th result of fft1024_wave_d
+__device__ __forceinline__ int wave_out_base_d() { const int lane = lane_id(); return (lane >> 2) + 64 * (lane & 3); }
+__device__ __forceinline__ int wave_out_index_d(int ob, int j) { return ob + 16 * (j & 3) + 256 * (j >> 2); }
 struct BinPairD { dcx xe, t; };
 __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
   const dcx bq{ zm.x, -zm.y };
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   const float* x = in + chan * n;
   const int lane = lane_id(), wave = wave_id();
   dcx* z = buf[wave];
-  const int ob = wave_out_base();
+  const int ob = wave_out_base_d();
   const BandLanePlan L = make_band_lane_plan(P, lane);
   const int64_t ngroups = (P.nframes + 3) / 4;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     wave_sync();
     fft1024_wave_d<false>(v, z, T);
 #pragma unroll
-    for (int j = 0; j < 16; j++) z[ob + 16 * j] = v[j];
+    for (int j = 0; j < 16; j++) z[wave_out_index_d(ob, j)] = v[j];
     wave_sync();
     float mk[8], mm[8];
 #pragma unroll
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
   const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
   const bool last_seg = f1 >= F;
-  const int ob = wave_out_base();
+  const int ob = wave_out_base_d();
   dcx* zw = buf[wave];
   float* bg = bgs[wave];
   uint64_t bands = 0;
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     wave_sync();
     fft1024_wave_d<false>(v, zw, T);
 #pragma unroll
-    for (int j = 0; j < 16; j++) zw[ob + 16 * j] = v[j];
+    for (int j = 0; j < 16; j++) zw[wave_out_index_d(ob, j)] = v[j];
     wave_sync();
     // ResonanceDetector.analyze (:194-233) and the gain of one bin (:361-382), with the reference's Float32Array stores
     auto bin_gain = [&](float mag, float& av_state, int band) -> double {
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     float2* yf = (float2*)zw;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      const int m = ob + 16 * j;
+      const int m = wave_out_index_d(ob, j);
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
       const float2 ws = window_pair_any(Wn, m);                    // the inverse's 1 / N is an exact scaling: applied to the window
       yf[m] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
