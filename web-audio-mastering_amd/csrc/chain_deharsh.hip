@@ -635,7 +635,7 @@ __device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_
   }
 }
 // magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
-__device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt(X.x * X.x + X.y * X.y)); }
+__device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt_fast(X.x * X.x + X.y * X.y)); }
 
 // ---- the reference's sequential f32 band sums without the 512-step dependent chain -----------------------------------------
 // bandEnergies[b] += mag * mag on a Float32Array (dynamic-processor.js:327-332) is s <- RN24(RN53(s + a)) bin after bin.  While the

@@ -92,6 +92,18 @@ __device__ __forceinline__ double tanh_fast(double x) {
   return copysign(m, x);
 }
 
+// sqrt(x) for x = 0 or x in [1e-280, 1e280], error <= 1 ulp: v_rsq_f64 and the Goldschmidt / Newton pair that ocml's sqrt uses,
+// without its range scaling and class checks (10 instructions against 16); used where the result is rounded to f32.
+__device__ __forceinline__ double sqrt_fast(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0 ? g : 0.0;
+}
+
 // exp(z) for |z| <= 40, relative error ~1e-15 (the exponential of tanh_fast on its own)
 __device__ __forceinline__ double exp_fast(double z) {
   const double k = rint(z * 1.4426950408889634);
