@@ -943,7 +943,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       }
       double gdb = bg[band];
       if (res > 0) gdb += -3.0 * (double)res * 0.2;
-      return (double)f32r(exp_fast(gdb / 20 * 2.30258509299404568402));   // 10^(gdb / 20); gains is a Float32Array (:320,:381)
+      return (double)f32r(exp_fast(gdb * (2.30258509299404568402 / 20)));   // 10^(gdb / 20) (a division by 20 would be a full IEEE
+                                                                            // sequence per bin); gains is a Float32Array (:320,:381)
     };
     const dcx* twB = twf + kTwl + kTwq;                            // (W2048 from LDS costs this kernel 600 spilled VGPRs: left in global memory)
 #pragma unroll 1                                                   // rolled: unrolled, the eight bodies' loads are hoisted and spill
