@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
           // 10^(-(20 log10(e/thr)) (1 - 1/ratio) / 20) = (e/thr)^-(1 - 1/ratio); stored to a Float32Array by the reference.
           // Evaluated to ~1e-15: a float32 intrinsic (1 ulp of the store) is enough for this stage alone, but the soft clipper
           // downstream multiplies a one-ulp difference by up to ~550 (tests/probe_hot_margin.py: 4e-5 on hot material).
-          g = f32r(pow_fast(e / P.glue_thr, -P.glue_k));
+          g = f32r(pow_fast(div_fast(e, P.glue_thr), -P.glue_k));       // (<= 1 ulp quotient: a third of the IEEE sequence)
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) w[c][k] = f32r((double)w[c][k] * (double)g);
