@@ -393,11 +393,11 @@ __device__ __forceinline__ double soft_knee_curve(double s, double ceiling, doub
   if (a <= knee_start) return s;
   double o;
   if (a <= ceiling) {
-    const double t = (a - knee_start) / (ceiling - knee_start);
+    const double t = div_fast(a - knee_start, ceiling - knee_start);      // quotients to <= 1 ulp (div_fast): the result is an f32 store
     const double blend = t * t * (3 - 2 * t);
     o = a + (ceiling - a) * blend * 0.5;
   } else {
-    const double nrm = (a - ceiling) / ceiling;
+    const double nrm = div_fast(a - ceiling, ceiling);
     const double comp = 1 - tanh_fast(nrm * 2) * 0.1;
     o = fmin(ceiling, a * comp);
   }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
       double r = y3;
       if (base + k >= 3) {
         const double m = P.lib_twin ? interp_peak3(y0, y1, y2, y3) : true_peak4(y0, y1, y2, y3);
-        if (m > P.ceil_lin) r = y3 * (P.ceil_lin / m);
+        if (m > P.ceil_lin) r = y3 * div_fast(P.ceil_lin, m);
       }
       o[k] = f32r(soft_knee_curve(r, P.ceil_lin, P.knee_start));
       y0 = y1; y1 = y2; y2 = y3;
