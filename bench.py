@@ -5,40 +5,55 @@
 
 A step = one pass of the hot path over one batch of synthetic 3-min stereo 48 kHz
 tracks already resident in HBM: the full export chain + LUFS/true-peak metering
-(`--workload chain`, BASELINE.json configs[2] sharded track-wise: `--tracks-per-gpu`
-tracks on each GPU; the default, 1,024, is the whole configs[2] batch on one GPU) or metering only
-(`--workload meter`, configs[0]).  Tracks are independent, so ranks never exchange
-audio: weak scaling, no data-path collective; torch.distributed is
-used only for the barrier and the max-over-ranks reduction of the step time.
+(`--workload chain`, BASELINE.json configs[2]) or metering only (`--workload meter`,
+configs[0]).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed
-on the launch stream through the library's profiling hooks) and `cpu_baseline`
-(the CPU oracle timed on a bounded sample, rank 0, N = 1 only).
+N > 1.  The batch is the FIXED 1,024-track batch of configs[2], sharded track-wise:
+rank r renders tracks [ceil(r T / N), ceil((r + 1) T / N)) (`wam_dist.shard_range`), so the
+line reports `"scaling": "strong"`.  `--tracks-per-gpu X` switches to X tracks on every GPU
+(`"scaling": "weak"`).  Tracks are independent, so ranks never exchange audio: no data-path
+collective; torch.distributed carries only the barrier, the max-over-ranks
+reduction of the step time and the per-track scalars that rank 0 prints.
+
+Launch.  Under an external launcher (`python -m torch.distributed.run ... bench.py --gpus N`)
+the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Without one
+(`python bench.py --gpus N`, WORLD_SIZE unset) this process starts the N rank processes itself
+- fresh children, before anything here has touched the GPU - relays rank 0's JSON line and
+exits with the worst exit code.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the
+launch stream through the library's profiling hooks), `roofline_valu` (the same kernel and
+the whole chain against the f64 VALU issue peak, instruction counts from the committed PMC
+passes) and `cpu_baseline` (the CPU oracle timed on a bounded sample, rank 0, N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "web-audio-mastering_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import torch  # noqa: E402  (first: libwam_hip.so must bind to the same HIP runtime as torch)
-import torch.distributed as dist  # noqa: E402
-import wam  # noqa: E402
-import wam_dist  # noqa: E402
-
 SR = 48000
 SECONDS = 180
 NCH = 2
 N = SR * SECONDS
+BATCH_TRACKS = 1024            # BASELINE.json configs[2] / configs[4]: the corpus
 
 # Settings of configs[1]/[2] (SURVEY.md 8d "C2"): UI defaults (web/index.html:178-295)
 # + glue compression + the 'aifix' EQ preset (web/lib/presets/eq.js:21).
-C2_SETTINGS = dict(wam.DEFAULT_SETTINGS, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1, eqHigh=2)
+DEFAULT_SETTINGS = dict(
+    normalizeLoudness=True, targetLufs=-14, truePeakLimit=True, truePeakCeiling=-1, cleanLowEnd=True,
+    glueCompression=False, deharsh=True, stereoWidth=100, centerBass=True, cutMud=False, addAir=True,
+    tapeWarmth=True, autoLevel=False, addPunch=True, inputGain=0,
+    eqLow=0, eqLowMid=0, eqMid=0, eqHighMid=0, eqHigh=0)
+C2_SETTINGS = dict(DEFAULT_SETTINGS, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1, eqHigh=2)
 SYNTH = dict(amp=1.6, dc=0.0, clickAmp=0.6)
 
 # algorithmic bytes per sample-channel of each kernel (DESIGN.md "Kernels")
@@ -60,6 +75,8 @@ KERNEL_BYTES = {
     "k_lim_gain": 8,       # read x + transient map, write gain envelope
     "k_lim_apply": 10,     # read x + envelope, write y
 }
+VALU_PEAK = 256 * 4 * 64 * 2.4e9 / 4       # f64 VALU lane-instructions / s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz, one issue per 4 cycles
+GROUP = 256      # tracks per render group inside the library (csrc/chain_api.hip): one launch of a chain kernel covers a group
 
 
 class SynthOpts(C.Structure):
@@ -68,8 +85,9 @@ class SynthOpts(C.Structure):
                 ("quiet2_from", C.c_int64), ("quiet2_to", C.c_int64), ("quiet2_gain", C.c_double)]
 
 
-def synth_dev(t, ntracks, idx0, opts, amp_step=0.0, sr=SR):
-    o = SynthOpts(opts.get("amp", 1.0), opts.get("dc", 0.0), opts.get("clickAmp", 0.0), -1, -1, 0.0, -1, -1, 0.0)
+def synth_dev(t, ntracks, idx0, opts, amp_step=0.0, sr=SR, amp0=None):
+    import wam
+    o = SynthOpts(opts.get("amp", 1.0) if amp0 is None else amp0, opts.get("dc", 0.0), opts.get("clickAmp", 0.0), -1, -1, 0.0, -1, -1, 0.0)
     rc = wam.lib().wam_synth_dev(C.c_void_p(t.data_ptr()), C.c_int(ntracks), C.c_int(NCH), C.c_int64(t.shape[-1]), C.c_double(sr),
                                  C.c_int(idx0), C.byref(o), C.c_double(amp_step), C.c_void_p(0))
     if rc:
@@ -77,6 +95,7 @@ def synth_dev(t, ntracks, idx0, opts, amp_step=0.0, sr=SR):
 
 
 def profile_read():
+    import wam
     buf = C.create_string_buffer(1 << 16)
     wam.lib().wam_profile_read(buf, C.c_size_t(len(buf)))
     out = {}
@@ -86,37 +105,112 @@ def profile_read():
     return out
 
 
-GROUP = 256      # tracks per render group inside the library (csrc/chain_api.hip): one launch of a chain kernel covers a group
-
-
-def pmc_traffic(kernel, tracks_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_summary.csv: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH_SIZE doubled per the gfx950 correction)."""
+# ---- committed PMC passes (profiles/rNN_pmc_summary.csv: separate rocprofv3 --pmc runs of this same bench) --------------
+def _pmc_rows():
+    """kernel -> row of the newest committed PMC summary that has it (chain passes, then the meter-workload passes)."""
     import csv
-    for name in ("r01_pmc_summary.csv", "r01_pmc_meter_summary.csv"):      # chain passes, meter-workload passes
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
+    import glob
+    rows, tracks = {}, {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")) + glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_meter_summary.csv")))
+    for path in files:                                    # later rounds overwrite earlier ones
         with open(path) as f:
-            rows = list(csv.DictReader(f))
-        meta = [r for r in rows if r["kernel"] == "#tracks_per_launch"]
-        ref_tracks = float(meta[0]["launches"]) if meta else None
-        for r in rows:
-            if r["kernel"] == kernel:
-                try:
-                    b = (float(r["fetch_GB_per_launch_x2"]) + float(r["write_GB_per_launch"])) * 1e9
-                except ValueError:
-                    return None
-                if ref_tracks and ref_tracks != tracks_per_launch:
-                    b *= tracks_per_launch / ref_tracks          # traffic is proportional to the tracks a launch covers
-                return b
-    return None
+            rs = list(csv.DictReader(f))
+        meta = [r for r in rs if r["kernel"] == "#tracks_per_launch"]
+        ref = float(meta[0]["launches"]) if meta else None
+        for r in rs:
+            if not r["kernel"].startswith("#"):
+                rows[r["kernel"]] = r
+                tracks[r["kernel"]] = ref
+                r["_file"] = os.path.basename(path)
+    return rows, tracks
+
+
+def pmc_traffic(kernel, tracks_per_launch, rows=None, tracks=None):
+    """HBM bytes per launch of `kernel`: FETCH_SIZE (doubled per the gfx950 correction) + WRITE_SIZE, scaled to the tracks a launch covers."""
+    if rows is None:
+        rows, tracks = _pmc_rows()
+    r = rows.get(kernel)
+    if not r:
+        return None
+    try:
+        b = (float(r["fetch_GB_per_launch_x2"]) + float(r["write_GB_per_launch"])) * 1e9
+    except ValueError:
+        return None
+    ref = tracks.get(kernel)
+    if ref and ref != tracks_per_launch:
+        b *= tracks_per_launch / ref
+    return b
+
+
+def pmc_instr(kernel, rows):
+    """VALU lane-instructions per sample-channel of `kernel` (SQ_INSTS_VALU x 64 / sample-channels of the profiled launch)."""
+    r = rows.get(kernel)
+    try:
+        return float(r["valu_lane_instr_per_sample_channel"]) if r else None
+    except ValueError:
+        return None
+
+
+# ---- CPU baseline -------------------------------------------------------------------------------------------------------
+_CPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import json
+import oracle_lib as O
+wl, sr, secs = sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+settings, synth = json.loads(sys.argv[6]), json.loads(sys.argv[7])
+idx = [int(a) for a in sys.argv[8:]]
+O.lib()
+print("ready", flush=True)
+sys.stdin.readline()                      # all workers start together
+t0 = time.perf_counter()
+for i in idx:
+    x = O.synth(i, 2, secs * sr, sr, synth)
+    if wl == "chain":
+        O.render_chain(x, sr, settings, "export")
+    elif wl == "stft":
+        O.stft_db(x, sr, 4096, 1024)
+    else:
+        O.measure_lufs(x, sr); O.true_peak_db(x)
+print(time.perf_counter() - t0, flush=True)
+"""
+
+
+def cpu_all_cores(kind, sr, secs, per_proc):
+    """The oracle on every host core this job may use: P processes, track-sharded, `per_proc` whole tracks each, started together.
+    P = min(16, cpu_count): the GPU box hands a one-GPU job 16 of its cores."""
+    procs_n = max(1, min(16, os.cpu_count() or 1))
+    procs = []
+    for p in range(procs_n):
+        idx = [str(1000 + p * per_proc + k) for k in range(per_proc)]
+        procs.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, os.path.join(ROOT, "tests"), os.path.join(ROOT, "web-audio-mastering_amd", "python"),
+                                       kind, str(sr), str(secs), json.dumps(C2_SETTINGS), json.dumps(SYNTH)] + idx,
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1")))
+    try:
+        for p in procs:
+            assert p.stdout.readline().strip() == "ready"
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        for p in procs:
+            p.stdout.readline()
+        dt = time.perf_counter() - t0
+        for p in procs:
+            p.wait(timeout=30)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    tracks = procs_n * per_proc
+    return {"value": tracks * secs / dt, "unit": "x realtime (audio-s/s)", "processes": procs_n, "kind": "port",
+            "sample": f"{tracks} tracks x {secs} s, {per_proc} per process, {procs_n} single-threaded oracle processes started together, {dt:.1f} s wall"}
 
 
 def cpu_baseline(workload, sr=SR):
     """Oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload: whole tracks of the
-    workload's shape (3-min stereo; a 60 s excerpt for the long-form case), one after the other on one core, until about
-    10 s of CPU time have been spent."""
+    workload's shape (3-min stereo; a 60 s excerpt for the long-form case), one after the other on ONE core (the reference is
+    single-threaded per worker), until about 10 s of CPU time have been spent; then, for the batch workloads, the same port on
+    all the host cores of this job, track-sharded over processes."""
     import oracle_lib as O
     chain = workload in ("chain", "single", "longform")
     secs = 60 if workload == "longform" else 180
@@ -133,9 +227,107 @@ def cpu_baseline(workload, sr=SR):
             O.true_peak_db(x)
         dt += time.perf_counter() - t0
         done += 1
-    return {"value": done * secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port",
-            "sample": f"{done} track(s) x {secs} s stereo {sr // 1000} kHz, same synthetic generator and settings, oracle/wam_oracle.c "
-                      f"(C restatement of the reference JS, one thread), {dt:.1f} s of CPU time"}
+    out = {"value": done * secs / dt, "unit": "x realtime (audio-s/s)", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+           "sample": f"{done} track(s) x {secs} s stereo {sr // 1000} kHz, same synthetic generator and settings, oracle/wam_oracle.c "
+                     f"(C restatement of the reference JS, one thread), {dt:.1f} s of CPU time"}
+    if workload in ("chain", "meter", "stft"):
+        kind = "chain" if chain else workload
+        per_core_s = dt / done
+        per_proc = max(1, min(8, int(round(10.0 / per_core_s))))          # ~10 s of wall time
+        try:
+            out["all_cores"] = cpu_all_cores(kind, sr, secs, per_proc)
+        except Exception as e:                                              # a baseline must never sink the bench line
+            out["all_cores"] = {"error": str(e)}
+    return out
+
+
+# ---- self-launch ----------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
+    """Start `n` rank processes of `script` (default: this file) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set, relay rank 0's stdout to ours and every rank's stderr (and the other ranks' stdout) to stderr with a rank prefix.
+    The parent never initialises the GPU; children are fresh interpreters.  Returns the worst exit code."""
+    script = script or os.path.abspath(__file__)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WAM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-u", script] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+
+    def pump(stream, sink, prefix):
+        for line in stream:
+            sink.write(prefix + line)
+            sink.flush()
+
+    threads = []
+    for r, p in enumerate(procs):
+        threads.append(threading.Thread(target=pump, args=(p.stdout, sys.stdout if r == 0 else sys.stderr, "" if r == 0 else f"[rank {r}] "), daemon=True))
+        threads.append(threading.Thread(target=pump, args=(p.stderr, sys.stderr, f"[rank {r}] "), daemon=True))
+    for t in threads:
+        t.start()
+    deadline = time.time() + timeout if timeout else None
+    worst = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is not None:
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:            # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+        if deadline and time.time() > deadline:
+            for q in pending:
+                q.kill()
+            worst = worst or 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    for t in threads:
+        t.join(timeout=5)
+    return worst
+
+
+class stdout_to_stderr:
+    """gloo announces its connections on the C stdout; the bench contract is ONE JSON line there, so fd 1 points at fd 2 meanwhile."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def resolve_shard(args, rank, world):
+    """(tracks of this rank, first global track index, total tracks, scaling) for the batch workloads."""
+    import wam_dist
+    if args.workload in ("single", "longform"):
+        T = args.tracks_per_gpu or 1
+        return T, rank * T, world * T, "weak"            # one track does not shard: replicas only (DESIGN.md 7)
+    if args.tracks_per_gpu:
+        T = args.tracks_per_gpu
+        return T, rank * T, world * T, "weak"
+    total = args.tracks or BATCH_TRACKS
+    lo, hi = wam_dist.shard_range(total, rank, world)
+    return hi - lo, lo, total, "strong"
 
 
 def main():
@@ -143,26 +335,60 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tracks-per-gpu", type=int, default=None, help="default 1024 (chain, meter, stft), 1 (single, longform)")
+    ap.add_argument("--tracks", type=int, default=None, help=f"total tracks of the batch, sharded over the ranks (default {BATCH_TRACKS}: BASELINE configs[2]; strong scaling)")
+    ap.add_argument("--tracks-per-gpu", type=int, default=None, help="weak-scaling mode: this many tracks on EVERY GPU (default for single / longform: 1)")
     ap.add_argument("--workload", choices=["chain", "meter", "single", "longform", "stft"], default="chain",
                     help="chain: configs[2] (default, the bench line); meter: configs[0] batched; single: configs[1], one 3-min track; "
                          "longform: configs[3], one 60-min 96 kHz track; stft: configs[4], 4096-point STFT hop 1024 over the corpus")
+    ap.add_argument("--seconds", type=int, default=None, help="track length (default 180; 3600 for longform) - shorter tracks are for rehearsals only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plan", action="store_true", help="resolve the launch (ranks, shards, scaling), rendezvous over gloo, print the plan as JSON; touches no GPU")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wam_tune knob for an experiment (e.g. dh_exact=1); recorded in config")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no external launcher: start the ranks ourselves, before anything in this process has touched the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
+
+    import torch  # noqa: E402  (first: libwam_hip.so must bind to the same HIP runtime as torch)
+    import torch.distributed as dist  # noqa: E402
+    import wam_dist  # noqa: E402
+
     # WAM_BENCH_REHEARSAL=1: run the N-rank code path on a box with ONE GPU (all ranks on cuda:0, gloo for the three collectives);
-    # a correctness rehearsal of the sharding / gathering plumbing only - its numbers mean nothing.
+    # a correctness rehearsal of the launch / sharding / gathering plumbing only - its numbers mean nothing.
     rehearsal = os.environ.get("WAM_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+
+    if args.plan:
+        if world > 1:
+            with stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        T, idx0, total, scaling = resolve_shard(args, rank, world)
+        table = wam_dist.gather_track_scalars(torch.tensor([[float(idx0 + t), float(rank)] for t in range(T)], dtype=torch.float64).reshape(T, 2), total)
+        if rank == 0:
+            owners = [int(v) for v in table[:, 1].tolist()]
+            print(json.dumps({"plan": True, "n_gpus": world, "workload": args.workload, "tracks_total": int(table.shape[0]), "scaling": scaling,
+                              "shards": [[owners.index(r), len(owners) - owners[::-1].index(r)] if r in owners else [0, 0] for r in range(world)],
+                              "track_index_ok": [int(v) for v in table[:, 0].tolist()] == list(range(int(table.shape[0]))),
+                              "self_launched": os.environ.get("WAM_BENCH_SELF_LAUNCHED") == "1"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import wam  # noqa: E402
+    if world > 1:
         if rehearsal:
             torch.cuda.set_device(0)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            with stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -179,18 +405,24 @@ def main():
     chain_like = wl in ("chain", "single", "longform")
     if wl == "longform":
         SR, SECONDS = 96000, 3600
+    if args.seconds:
+        SECONDS = args.seconds
     N = SR * SECONDS
-    T = args.tracks_per_gpu if args.tracks_per_gpu else (1 if wl in ("single", "longform") else 1024)
-    x = torch.empty((T, NCH, N), dtype=torch.float32, device=dev)
-    synth_dev(x, T, rank * T, SYNTH, amp_step=0.3 / max(T, 1), sr=SR)      # distinct seed per track, levels 1.6 .. 1.9
+    T, idx0, total, scaling = resolve_shard(args, rank, world)
+    amp_step = 0.3 / max(total, 1)                              # distinct seed per track (= its global index), levels 1.6 .. 1.9 over the batch
+    x = torch.empty((max(T, 1), NCH, N), dtype=torch.float32, device=dev)
+    if T > 0:
+        synth_dev(x, T, idx0, SYNTH, amp_step=amp_step, sr=SR, amp0=SYNTH["amp"] + idx0 * amp_step)
     y = torch.empty_like(x) if chain_like else None
     NFFT, HOP = 4096, 1024
     if wl == "stft":
         nframes = (N - NFFT) // HOP + 1
-        spec = torch.empty((T, nframes, NFFT // 2), dtype=torch.float32, device=dev)
+        spec = torch.empty((max(T, 1), nframes, NFFT // 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step():
+        if T == 0:
+            return [] if chain_like else ([], [])
         if chain_like:
             return wam.batch_render_dev(x.data_ptr(), y.data_ptr(), T, NCH, N, SR, C2_SETTINGS, "export")
         if wl == "stft":
@@ -220,62 +452,101 @@ def main():
     # per-track scalars of every shard, in global track order (the only data that leaves a rank)
     if chain_like:
         local = [[r.lufs, r.true_peak_db, r.lufs_in, r.gain_db] for r in res]
+        k = 4
     elif wl == "stft":
         local = [[float(spec[t].max()), float(spec[t, :, 1:].float().mean())] for t in range(min(T, 4))] + [[0.0, 0.0]] * max(0, T - 4)
+        k = 2
     else:
         local = [[float(a), float(b)] for a, b in zip(res[0], res[1])]
-    table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64), world * T, comm)
+        k = 2
+    table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64).reshape(T, k), total, comm)
 
     if rank == 0:
-        audio_s = world * T * SECONDS * args.steps
+        audio_s = total * SECONDS * args.steps
         ms_per_step = dt / args.steps * 1e3
-        # dominant kernel by total device time
+        rows, rtracks = _pmc_rows()
+        # dominant kernel by total device time (rank 0's shard; every rank runs the same kernels on its own tracks)
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roofline = None
+        roofline_valu = None
+        tracks_per_launch = min(T, GROUP) if chain_like else T
+        units_per_launch = tracks_per_launch * NCH * N          # sample-channels one launch of a kernel covers
         if dom:
             name, (cnt, total_ms) = dom
             launches_per_step = cnt / args.steps
             avg_ms = total_ms / cnt
             bpsc = KERNEL_BYTES.get(name)
-            tracks_per_launch = min(T, GROUP) if chain_like else T
             if name == "k_stft":
                 bpsc = 12 / NCH                     # 12 B per MONO sample: 4 read (both channels: 8) ... stated per sample-channel
             if bpsc is not None:
-                alg_bytes = bpsc * tracks_per_launch * NCH * N
+                alg_bytes = bpsc * units_per_launch
                 achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                            "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch), "avg_launch_ms": avg_ms,
+                            "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch, rows, rtracks), "avg_launch_ms": avg_ms,
                             "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
-                            "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): the chain needs ~2,600 VALU "
-                                     "lane-instructions per 16 algorithmic bytes against a machine balance of ~5 per byte") if chain_like else
+                            "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): see roofline_valu") if chain_like else
                                     ("two f64 K-weighting biquad scans + the 4-point peak interpolation per 4-byte sample: VALU-bound "
                                      "(DESIGN.md 5)" if wl == "meter" else "f32 butterflies in LDS; see DESIGN.md 5")}
             else:
                 roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                             "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}
-        kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+            ipu = pmc_instr(name, rows)
+            if ipu is not None:
+                ach = ipu * units_per_launch / (avg_ms * 1e-3)
+                roofline_valu = {"bound": "valu_f64", "kernel": name, "instr_per_unit": ipu, "unit_of_work": "sample-channel", "units_per_launch": units_per_launch,
+                                 "avg_launch_ms": avg_ms, "achieved": ach, "peak": VALU_PEAK, "unit": "lane-instr/s", "frac": ach / VALU_PEAK,
+                                 "source": rows[name]["_file"]}
+        kernels = {k_: {"launches": v[0], "total_ms": round(v[1], 3)} for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         kernel_ms_per_step = sum(v[1] for v in prof.values()) / args.steps
         chain_bytes = (16 if chain_like else (6 if wl == "stft" else 4)) * T * NCH * N
+        if roofline_valu is not None and kernel_ms_per_step > 0:
+            # the whole step against the same peak: sum over kernels of (instructions per unit x units the kernel covered in a step)
+            instr = 0.0
+            missing = []
+            for k_, (cnt, _) in prof.items():
+                ipu = pmc_instr(k_, rows)
+                if ipu is None:
+                    missing.append(k_)
+                    continue
+                instr += ipu * units_per_launch * (cnt / args.steps)      # per launch x launches per step
+            roofline_valu["chain"] = {"instr_per_unit": instr / (T * NCH * N), "kernel_ms_per_step": kernel_ms_per_step,
+                                      "achieved": instr / (kernel_ms_per_step * 1e-3), "frac": instr / (kernel_ms_per_step * 1e-3) / VALU_PEAK,
+                                      "kernels_without_counters": missing}
+        traffic_step = None
+        if prof:
+            tb_, ok = 0.0, True
+            for k_, (cnt, _) in prof.items():
+                b = pmc_traffic(k_, tracks_per_launch, rows, rtracks)
+                if b is None:
+                    ok = False
+                    continue
+                tb_ += b * (cnt / args.steps)                      # per launch x launches per step
+            traffic_step = tb_ if ok or tb_ > 0 else None
+        cfg_workload = ({"chain": f"BASELINE configs[2]: {total} tracks" + (f", {T} on rank 0" if world > 1 else ""), "single": "BASELINE configs[1]: one track",
+                         "longform": "BASELINE configs[3]: one long-form track"}.get(wl, "") +
+                        f" x {SECONDS // 60}-min stereo {SR // 1000} kHz, full export chain "
+                        "(input gain, de-harsh, exciter, tape warmth, punch, 30 Hz HPF + 18 kHz LPF, 5-band EQ 'aifix', glue comp, "
+                        "mono-bass M/S, -14 LUFS normalise, soft clip, TP limiter) + LUFS/true-peak of the result"
+                        if chain_like else
+                        f"BASELINE configs[4]: {total} tracks x 3-min stereo 48 kHz, 4096-point periodic-Hann STFT, hop 1024, of the mono mix, dB per bin"
+                        if wl == "stft" else
+                        f"BASELINE configs[0] batched: {total} tracks x 3-min stereo 48 kHz, integrated LUFS + true peak")
         out = {
             "metric": ("x realtime (audio-s/s) full master chain+LUFS" if chain_like else
                        "x realtime (audio-s/s) 4096-pt STFT hop 1024" if wl == "stft" else "x realtime (audio-s/s) LUFS+true-peak meter"),
             "value": audio_s / dt, "unit": "x realtime (audio-s/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, numbers meaningless)" if rehearsal else ""),
-            "config": {"workload": ({"chain": f"BASELINE configs[2]: {T} tracks/GPU", "single": "BASELINE configs[1]: one track",
-                                     "longform": "BASELINE configs[3]: one long-form track"}[wl] +
-                                    f" x {SECONDS // 60}-min stereo {SR // 1000} kHz, full export chain "
-                                    "(input gain, de-harsh, exciter, tape warmth, punch, 30 Hz HPF + 18 kHz LPF, 5-band EQ 'aifix', glue comp, "
-                                    "mono-bass M/S, -14 LUFS normalise, soft clip, TP limiter) + LUFS/true-peak of the result"
-                                    if chain_like else
-                                    f"BASELINE configs[4]: {T} tracks/GPU x 3-min stereo 48 kHz, 4096-point periodic-Hann STFT, hop 1024, of the mono mix, dB per bin"
-                                    if wl == "stft" else
-                                    f"BASELINE configs[0] batched: {T} tracks/GPU x 3-min stereo 48 kHz, integrated LUFS + true peak"),
-                       "tracks_per_gpu": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
+            "config": {"workload": cfg_workload, "tracks_total": total, "tracks_per_gpu": T if scaling == "weak" else None,
+                       "tracks_rank0": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
                        "settings": C2_SETTINGS if chain_like else None, "parallelism": f"track-sharded x{world}, no collective",
+                       **({"eq": "spec-defined (Web Audio biquad formulas), parity unpinned: the reference's EQ stage throws (SURVEY.md 0.1)"} if chain_like else {}),
                        **({"tune": args.tune} if args.tune else {})},
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
             "chain_hbm_frac": (chain_bytes / (kernel_ms_per_step * 1e-3) / 8e12) if kernel_ms_per_step > 0 else None,
+            "chain_algorithmic_bytes": chain_bytes,
+            "chain_traffic_bytes": traffic_step,
             "kernel_ms_per_step": kernel_ms_per_step,
             "kernels": kernels,
         }

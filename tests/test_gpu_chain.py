@@ -18,9 +18,6 @@ PCM_TOL = 1e-5
 LUFS_TOL = 0.01
 TP_TOL = 0.01
 
-HAVE_DEHARSH = hasattr(wam.lib(), "wam_deharsh")
-
-
 def maxerr(a, b):
     a = np.stack([np.asarray(x, dtype=np.float64) for x in a])
     b = np.stack([np.asarray(x, dtype=np.float64) for x in b])
@@ -42,8 +39,6 @@ CHAINS = ["chain_nodeharsh_1s", "chain_core_1s", "chain_ceiling0_1s", "chain_pre
 @pytest.mark.parametrize("name", CHAINS)
 def test_chain_vs_reference_golden(golden, name):
     c = golden[name]
-    if c["settings"].get("deharsh") and not HAVE_DEHARSH:
-        pytest.skip("de-harsh not built")
     x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
     seen = []
     y, res = wam.render_full_chain(x, c["sr"], c["settings"], c["mode"], on_progress=lambda p, s: seen.append((p, s)) or False)
@@ -72,8 +67,6 @@ SETTINGS = [
 @pytest.mark.parametrize("over", SETTINGS)
 @pytest.mark.parametrize("deharsh", [False, True])
 def test_chain_vs_oracle(over, deharsh):
-    if deharsh and not HAVE_DEHARSH:
-        pytest.skip("de-harsh not built")
     sr, n = 48000, 60000
     x = O.synth(50, 2, n, sr, {"amp": 1.8, "clickAmp": 0.7, "dc": 0.001})
     s = dict(wam.DEFAULT_SETTINGS, deharsh=deharsh, **over)
@@ -120,8 +113,6 @@ def test_cancel():
 @pytest.mark.parametrize("name", ["chain_180s_nodeharsh", "chain_180s_defaults"])
 def test_chain_180s_vs_reference_golden(golden, name):
     c = golden[name]
-    if c["settings"].get("deharsh") and not HAVE_DEHARSH:
-        pytest.skip("de-harsh not built")
     x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
     y, res = wam.render_full_chain(x, c["sr"], c["settings"], "export")
     close(res.lufs, G.num(c["lufs"]), LUFS_TOL)
@@ -138,7 +129,7 @@ def test_chain_180s_vs_reference_golden(golden, name):
 def test_batch_render_dev_matches_single():
     import torch
     sr, n, nt = 48000, 50000, 3
-    s = dict(wam.DEFAULT_SETTINGS, deharsh=HAVE_DEHARSH, glueCompression=True)
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=True, glueCompression=True)
     tracks = [O.synth(60 + t, 2, n, sr, {"amp": 1.2 + 0.4 * t, "clickAmp": 0.5}) for t in range(nt)]
     dev = torch.from_numpy(np.stack([np.stack(t) for t in tracks])).cuda()
     out = torch.empty_like(dev)
@@ -179,8 +170,6 @@ def test_hot_material_margin():
     try:
         for over in (dict(targetLufs=-9, truePeakCeiling=-0.3, inputGain=6), dict(targetLufs=-7, inputGain=3, glueCompression=True)):
             for dh, exact in ((False, 1), (True, 1), (True, 0)):
-                if dh and not HAVE_DEHARSH:
-                    continue
                 wam.tune("dh_exact", exact)
                 s = dict(wam.DEFAULT_SETTINGS, deharsh=dh, **over)
                 y, _ = wam.render_full_chain(x, sr, s, "export")
@@ -204,9 +193,8 @@ def test_ragged_fx_and_chain(n, nch):
     assert maxerr(wam.apply_exciter(x, sr), O.exciter(x, sr)) <= PCM_TOL
     assert maxerr(wam.apply_tape_warmth(x, sr), O.warmth(x, sr)) <= PCM_TOL
     assert maxerr(wam.apply_multiband_transient(x, sr), O.punch(x, sr)) <= PCM_TOL
-    if HAVE_DEHARSH:
-        assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= PCM_TOL
-    s = dict(wam.DEFAULT_SETTINGS, deharsh=HAVE_DEHARSH, glueCompression=True, eqLow=1, eqHigh=2, cutMud=True)
+    assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= PCM_TOL
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=True, glueCompression=True, eqLow=1, eqHigh=2, cutMud=True)
     y, res = wam.render_full_chain(x, sr, s, "export")
     yo, ro = O.render_chain(x, sr, s, "export")
     assert maxerr(y, yo) <= PCM_TOL
@@ -222,8 +210,7 @@ def test_empty_input_everywhere():
                wam.apply_mastering_soft_clip):
         out = fn(z, sr)
         assert len(out) == 2 and len(out[0]) == 0
-    if HAVE_DEHARSH:
-        assert len(wam.process_hybrid_dynamic(z, sr)[0]) == 0
+    assert len(wam.process_hybrid_dynamic(z, sr)[0]) == 0
     y, res = wam.render_full_chain(z, sr, dict(wam.DEFAULT_SETTINGS), "export")
     assert len(y[0]) == 0
     assert wam.measure_lufs(z, sr) == -14.0 and wam.find_true_peak(z) == float("-inf")
@@ -238,7 +225,7 @@ def test_chain_other_sample_rates(sr):
     switched off: the reference's filters are unstable there and both sides only produce garbage."""
     n = int(sr * 1.5) + 13
     x = O.synth(90, 2, n, sr, {"amp": 1.7, "clickAmp": 0.6})
-    s = dict(wam.DEFAULT_SETTINGS, deharsh=HAVE_DEHARSH, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1,
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=True, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1,
              eqHigh=2 if sr >= 32000 else 0)
     y, res = wam.render_full_chain(x, sr, s, "export")
     yo, ro = O.render_chain(x, sr, s, "export")
@@ -257,7 +244,7 @@ def test_chain_random_settings():
     for k in range(40):
         b = lambda: bool(rng.integers(0, 2))
         s = dict(normalizeLoudness=b(), targetLufs=float(rng.choice([-23, -16, -14, -11, -9, -7])), truePeakLimit=b(),
-                 truePeakCeiling=float(rng.choice([0, -0.1, -0.3, -1, -2, -3])), cleanLowEnd=b(), glueCompression=b(), deharsh=b() and HAVE_DEHARSH,
+                 truePeakCeiling=float(rng.choice([0, -0.1, -0.3, -1, -2, -3])), cleanLowEnd=b(), glueCompression=b(), deharsh=b(),
                  stereoWidth=float(rng.choice([0, 50, 100, 100, 150, 200])), centerBass=b(), cutMud=b(), addAir=b(), tapeWarmth=b(), autoLevel=False,
                  addPunch=b(), inputGain=float(rng.choice([-12, -4.5, 0, 0, 3, 6, 12])),
                  eqLow=float(rng.integers(-12, 13)) * float(b()), eqLowMid=float(rng.integers(-12, 13)) * float(b()), eqMid=float(rng.integers(-12, 13)) * float(b()),

@@ -178,11 +178,6 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     width = std::fmax(0.0, std::fmin(2.0, w));
     do_stereo = st.center_bass || std::fabs(width - 1.0) > 1e-6;
   }
-  if (do_deharsh) {
-#ifndef WAM_HAVE_DEHARSH
-    set_error("de-harsh stage is not available in this build"); return WAM_ERR_INVALID;
-#endif
-  }
 
   // ---- plans
   MeterPlan mp; rc = make_meter_plan(nch, n, sr, -14.0, &mp); if (rc) return rc;
@@ -244,11 +239,9 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
   if (ig_db != 0) { rc = prog(0.10, "Applying input gain..."); if (rc) return rc; }
   if (do_deharsh) {
     rc = prog(0.15, "Applying hybrid dynamic processor..."); if (rc) return rc;
-#ifdef WAM_HAVE_DEHARSH
     float* dst = next_dst();
     rc = enqueue_deharsh(src, dst, T, nch, n, sr, pending_gain, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
-#endif
   }
   if (do_exc) {
     rc = prog(0.3, "Applying exciter..."); if (rc) return rc;
