@@ -68,7 +68,8 @@ typedef struct wam_result {
 } wam_result;
 
 /* Progress callback, same fractions/status strings as sendProgress(),
- * dsp-worker.js:69-71,1475-1664.  Return non-zero to cancel. */
+ * dsp-worker.js:69-71,1475-1664, in the same order - the look-ahead limiter's own messages (:302,364,427,448)
+ * included, wherever the worker runs that limiter (RENDER_FULL_CHAIN, NORMALIZE, APPLY_LIMITER).  Return non-zero to cancel. */
 typedef int (*wam_progress_cb)(double progress, const char* status, void* user);
 
 /* ---- library ------------------------------------------------------------ */
@@ -184,13 +185,15 @@ typedef struct wam_normalize_result {
   int32_t measured;   /* 0 when loudness was not finite and the input was returned unchanged */
 } wam_normalize_result;
 int wam_normalize(const float* const* ch, int nch, int64_t n, double sample_rate,
-                  double target_lufs, double ceiling_db, float* const* out, wam_normalize_result* res);
+                  double target_lufs, double ceiling_db, float* const* out, wam_normalize_result* res,
+                  wam_progress_cb progress, void* user);   /* the message's own PROGRESS stream (:458,471,491 + the limiter's), may be NULL */
 
 /* applyLookaheadLimiterToChannels, dsp-worker.js:286-452 (message APPLY_LIMITER
  * :1380; DSPWorkerInterface.applyLimiter(), worker-interface.js:227). */
 int wam_limiter(const float* const* ch, int nch, int64_t n, double sample_rate,
                 double ceiling_linear, double lookahead_ms, double release_ms, double knee_db,
-                int preserve_transients, float* const* out);
+                int preserve_transients, float* const* out,
+                wam_progress_cb progress, void* user);     /* dsp-worker.js:302,364,427,448, then 1.0 'Complete' (:1673); may be NULL */
 
 /* applyLookaheadLimiter(audioBuffer, ...), web/lib/dsp/limiter.js:155-362: the library twin, which the sync API and
  * normalizeToLUFS (normalizer.js:83) call.  Same stages; its oversampled soft-knee pass starts the running maximum at 0

@@ -162,7 +162,8 @@ double ora_short_term_lufs(const float* const* ch, int nch, int64_t n, double sr
   const int64_t st = (int64_t)floor(position * sr);
   int64_t en = st + win; if (en > n) en = n;
   if ((double)(en - st) < (double)win * 0.5) return -INFINITY;
-  const float* sub[2];
+  const float* sub[64];                          /* any channel count the reference's loop takes (lufs.js:102-116); 64 here */
+  if (nch > 64) return NAN;
   for (int c = 0; c < nch; c++) sub[c] = ch[c] + st;
   return ora_measure_lufs(sub, nch, en - st, sr, -14, NULL, NULL, NULL);
 }

@@ -461,4 +461,6 @@ async function main() {
   say('wrote', path.join(OUT, 'golden.json'));
 }
 
-main().catch(e => { console.error(e); process.exit(1); });
+// (tests/golden/gen_shapes.mjs reuses the scratch copy and the helpers)
+export { prepareScratch, AB, toAB, chansOf, cloneChans, lufsDetail, num, saveF32, saveF64, saveU8, saveChans, stats };
+if (process.argv[1] && import.meta.url === pathToFileURL(process.argv[1]).href) main().catch(e => { console.error(e); process.exit(1); });

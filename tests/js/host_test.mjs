@@ -114,9 +114,8 @@ async function gpu() {
       ok(d <= 1e-5, `${name} ch${ch} max abs diff ${d}`);
     }
     ok(Math.abs(r.lufs - c.lufs) <= 0.01, `${name} lufs`);
-    // chain-level protocol (the worker's nested limiter messages aside, as in tests/test_gpu_chain.py)
-    const nested = new Set(['Analyzing transients...', 'Calculating gain envelope...', 'Applying limiting...']);
-    const want = c.progress.filter((p) => !nested.has(p[1]) && !p[1].startsWith('Processing channel'));
+    // the worker's whole PROGRESS stream, the limiter's own messages included (as in tests/test_gpu_chain.py)
+    const want = c.progress;
     for (let k = 0; k < 5 && seen.length < want.length; k++) await new Promise((res) => setTimeout(res, 10));   // let queued progress calls drain
     ok(seen.length === want.length, `${name} progress count ${seen.length} vs ${want.length}`);
     for (let i = 0; i < seen.length; i++) ok(seen[i][1] === want[i][1] && Math.abs(seen[i][0] - want[i][0]) < 1e-12, `${name} progress[${i}] ${seen[i]} vs ${want[i]}`);
@@ -166,6 +165,42 @@ async function gpu() {
     const bad = got.find((m) => m.id === 8);
     ok(bad.success === false && bad.error === 'Unknown message type: NO_SUCH_TYPE', `worker protocol: unknown type, got '${bad.error}'`);
     wk.terminate(); }
+  // NORMALIZE / APPLY_LIMITER: the messages' own PROGRESS streams (dsp-worker.js:458,471,491 and :302,364,427,448), through the
+  // Worker-shaped adapter and through the promise interface; meters with more than two channels and a non-4-hop sample rate
+  { const SH = JSON.parse(fs.readFileSync(path.join(DATA, 'shapes.json'), 'utf8')).cases;
+    const wk = new wam.WamWorker();
+    const ask = (type, data) => new Promise((resolve) => {
+      const msgs = []; wk.onmessage = (e) => { msgs.push(e.data); if (e.data.type !== 'PROGRESS') resolve(msgs); };
+      wk.postMessage({ type, id: 21, data }); });
+    const sameProgress = (got, want, what) => {
+      ok(got.length === want.length, `${what}: ${got.length} progress messages vs ${want.length}`);
+      for (let i = 0; i < Math.min(got.length, want.length); i++) ok(got[i][1] === want[i][1] && Math.abs(got[i][0] - want[i][0]) < 1e-12, `${what} progress[${i}] ${got[i]} vs ${want[i]}`); };
+    for (const name of ['msg_normalize_limited', 'msg_normalize_plain']) {
+      const c = SH[name]; const ab = track(c);
+      const msgs = await ask('NORMALIZE', { channels: [ab.getChannelData(0), ab.getChannelData(1)], sampleRate: c.sr, targetLUFS: c.target, ceilingDB: c.ceiling_db });
+      const reply = msgs[msgs.length - 1];
+      ok(reply.success === true && reply.result.limiterApplied === c.limiterApplied && Math.abs(reply.result.currentLUFS - c.currentLUFS) <= 0.01, `${name} reply`);
+      ok(maxAbsDiff(reply.result.channels[1], f32(c.out[1])) <= 1e-5, `${name} audio`);
+      sameProgress(msgs.filter((m) => m.type === 'PROGRESS').map((m) => [m.progress, m.status]), c.progress, `worker ${name}`);
+      const seen = []; const r = await w.normalize(ab, c.target, c.ceiling_db, (p, s) => seen.push([p, s]));
+      for (let k = 0; k < 5 && seen.length < c.progress.length; k++) await new Promise((res) => setTimeout(res, 10));
+      sameProgress(seen, c.progress, `interface ${name}`);
+      ok(maxAbsDiff(r.audioBuffer.getChannelData(0), f32(c.out[0])) <= 1e-5, `${name} interface audio`);
+    }
+    { const c = SH['msg_limiter']; const ab = track(c);
+      const msgs = await ask('APPLY_LIMITER', { channels: [ab.getChannelData(0), ab.getChannelData(1)], sampleRate: c.sr, ceilingLinear: c.ceiling_lin });
+      sameProgress(msgs.filter((m) => m.type === 'PROGRESS').map((m) => [m.progress, m.status]), c.progress, 'worker APPLY_LIMITER');
+      ok(maxAbsDiff(msgs[msgs.length - 1].result.channels[0], f32(c.out[0])) <= 1e-5, 'worker APPLY_LIMITER audio');
+      const seen = []; const r = await w.applyLimiter(ab, { ceilingLinear: c.ceiling_lin }, (p, s) => seen.push([p, s]));
+      for (let k = 0; k < 5 && seen.length < c.progress.length; k++) await new Promise((res) => setTimeout(res, 10));
+      sameProgress(seen, c.progress, 'interface applyLimiter');
+      ok(maxAbsDiff(r.audioBuffer.getChannelData(1), f32(c.out[1])) <= 1e-5, 'interface applyLimiter audio'); }
+    wk.terminate();
+    for (const name of ['meter_3ch_48k', 'meter_11025']) {
+      const c = SH[name]; const ab = track(c);
+      ok(Math.abs(wam.measureLUFS(ab) - c.lufs) <= 0.01 && Math.abs(wam.findTruePeak(ab) - c.tp_db) <= 0.01, `${name} through the JS surface`);
+      ok(Math.abs(wam.measureShortTermLUFS(ab, c.short_term[1][0]) - c.short_term[1][1]) <= 0.01, `${name} short-term`);
+    } }
   // normalize + terminate semantics
   { const c = golden['meter_10s_48k']; const ab = track(c);
     const r = await w.normalize(ab, -14, -1);

@@ -14,7 +14,7 @@ namespace wam {
 
 static thread_local std::string g_err;
 static thread_local int g_device = -1;
-static std::atomic<int> g_default_device{-1};   // set by the first wam_init; threads that never called wam_init use it
+static std::atomic<int> g_default_device{-1};   // set by every wam_init; threads that never called wam_init use the latest
 
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -22,16 +22,24 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 
-Tuning& tuning() { static Tuning t; return t; }
+static std::mutex g_tune_mu;
+static Tuning g_tuning;
+Tuning tuning() { std::lock_guard<std::mutex> lk(g_tune_mu); return g_tuning; }
 #ifdef WAM_COUNT_ITERS
 __device__ unsigned long long g_iter_stats[8];
 __device__ unsigned long long g_iter_hist[4];
 #endif
 
 // ---- workspace pool -----------------------------------------------------------
-struct PoolBlock { void* p; size_t bytes; int device; };
+// A block comes back to the pool when its DevBuf goes out of scope - on error paths possibly while kernels that use it are
+// still queued.  pool_free therefore records an event on the stream the calling entry point works on (StreamScope, thread-
+// local; the null stream by default) and the next owner waits for that event before it gets the block.
+struct PoolBlock { void* p; size_t bytes; int device; hipEvent_t idle; };
 static std::mutex g_pool_mu;
-static std::vector<PoolBlock> g_pool;                 // idle blocks
+static std::vector<PoolBlock> g_pool;                 // blocks not owned by a DevBuf
+static thread_local hipStream_t g_scope_stream = nullptr;
+StreamScope::StreamScope(hipStream_t s) : prev_(g_scope_stream) { g_scope_stream = s; }
+StreamScope::~StreamScope() { g_scope_stream = prev_; }
 
 void* pool_alloc(size_t bytes, size_t* granted) {
   const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(2) << 20) : 256;
@@ -46,9 +54,14 @@ void* pool_alloc(size_t bytes, size_t* granted) {
       if (best < 0 || b.bytes < g_pool[best].bytes) best = i;
     }
     if (best >= 0) {
-      void* p = g_pool[best].p; *granted = g_pool[best].bytes;
+      const PoolBlock b = g_pool[best];
       g_pool.erase(g_pool.begin() + best);
-      return p;
+      *granted = b.bytes;
+      if (b.idle) {                                     // the previous owner's last work on this block (usually long done)
+        if (hipEventQuery(b.idle) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b.idle); }
+        (void)hipEventDestroy(b.idle);
+      }
+      return b.p;
     }
   }
   void* p = nullptr;
@@ -65,8 +78,14 @@ void* pool_alloc(size_t bytes, size_t* granted) {
 void pool_free(void* p, size_t granted) {
   if (!p) return;
   int dev = 0; (void)hipGetDevice(&dev);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, g_scope_stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    (void)hipStreamSynchronize(g_scope_stream);      // no event: make the block idle the slow way
+  }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_pool.push_back(PoolBlock{p, granted, dev});
+  g_pool.push_back(PoolBlock{p, granted, dev, ev});
 }
 
 // ---- per-kernel timing ------------------------------------------------------
@@ -75,18 +94,21 @@ static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 
-void prof_begin(const char* name, hipStream_t s) {
-  if (!g_prof_on) return;
-  ProfEntry e; e.name = name;
-  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+// Returns the entry's ticket (-1: profiling off): several host threads may launch at once (wam_batch_render's workers), so
+// prof_end names the entry it closes instead of taking the newest one.
+int prof_begin(const char* name, hipStream_t s) {
+  if (!g_prof_on) return -1;
+  ProfEntry e; e.name = name; e.a = e.b = nullptr;
+  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { if (e.a) (void)hipEventDestroy(e.a); (void)hipGetLastError(); return -1; }
   (void)hipEventRecord(e.a, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(e);
+  return (int)g_prof.size() - 1;
 }
-void prof_end(hipStream_t s) {
-  if (!g_prof_on) return;
+void prof_end(int ticket, hipStream_t s) {
+  if (ticket < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, s);
+  if (ticket < (int)g_prof.size()) (void)hipEventRecord(g_prof[ticket].b, s);     // (wam_profile_read clears the log: callers read it between steps)
 }
 
 int ensure_device() {
@@ -98,8 +120,11 @@ int ensure_device() {
   return wam_init(d >= 0 ? d : 0);
 }
 
-static int check_audio(const float* const* ch, int nch, int64_t n) {
-  if (!ch || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
+// The meters take any channel count, like the reference's loops over numberOfChannels (lufs.js:28-65, true-peak.js:46-71);
+// kMaxMeterChannels only bounds the grid arithmetic.
+constexpr int kMaxMeterChannels = 64;
+static int check_audio(const float* const* ch, int nch, int64_t n, int max_nch = kMaxMeterChannels) {
+  if (!ch || nch < 1 || nch > max_nch || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld; 1..%d channels)", nch, (long long)n, max_nch); return WAM_ERR_INVALID; }
   for (int c = 0; c < nch; c++) if (!ch[c] && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
   return WAM_OK;
 }
@@ -115,6 +140,7 @@ static int upload(const float* const* ch, int nch, int64_t n, DevBuf& buf, hipSt
 
 static int meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sr, double fallback,
                      double* lufs, double* dbtp, double* block_ms, uint8_t* gate_mask, int64_t* nblocks_out, hipStream_t stream) {
+  const StreamScope scope(stream);
   MeterPlan pl;
   int rc = make_meter_plan(nch, n, sr, fallback, &pl);
   if (rc) return rc;
@@ -164,13 +190,18 @@ int wam_trim_workspace(void) {
   std::vector<wam::PoolBlock> blocks;
   { std::lock_guard<std::mutex> lk(wam::g_pool_mu); blocks.swap(wam::g_pool); }
   int cur = 0; (void)hipGetDevice(&cur);
-  for (const auto& b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+  for (const auto& b : blocks) {
+    (void)hipSetDevice(b.device);
+    if (b.idle) { (void)hipEventSynchronize(b.idle); (void)hipEventDestroy(b.idle); }
+    (void)hipFree(b.p);
+  }
   (void)hipSetDevice(cur);
   return WAM_OK;
 }
 int wam_tune(const char* key, int64_t value) {
   if (!key || value < 0) { wam::set_error("wam_tune: bad argument"); return WAM_ERR_INVALID; }
-  wam::Tuning& t = wam::tuning();
+  std::lock_guard<std::mutex> lk(wam::g_tune_mu);
+  wam::Tuning& t = wam::g_tuning;
   const std::string k = key;
   if (k == "dh_seg_frames" && (value == 0 || value >= 4)) t.dh_seg_frames = value;
   else if (k == "dh_warm_frames" && value >= 3) t.dh_warm_frames = value;
@@ -227,8 +258,7 @@ int wam_init(int device) {
   if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return WAM_ERR_INVALID; }
   if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
   g_device = device;
-  int expect = -1;
-  g_default_device.compare_exchange_strong(expect, device);
+  g_default_device.store(device);          // threads that never called wam_init (libuv workers) follow the LAST explicit choice
   return WAM_OK;
 }
 
@@ -270,29 +300,35 @@ int wam_short_term_lufs(const float* const* ch, int nch, int64_t n, double sampl
   int rc = check_audio(ch, nch, n); if (rc) return rc;
   if (!lufs || !(sample_rate > 0) || !(position >= 0)) { set_error("invalid short-term arguments"); return WAM_ERR_INVALID; }
   const int64_t win = (int64_t)std::floor(sample_rate * 3000 / 1000);              // lufs.js:93-96
-  const int64_t start = (int64_t)std::floor(position * sample_rate);
-  const int64_t end = start + win < n ? start + win : n;
+  const double sp = std::floor(position * sample_rate);
+  if (!(sp < (double)n)) { *lufs = -INFINITY; return WAM_OK; }                     // past the end (also keeps the cast below in range): :98-100
+  const int64_t start = (int64_t)sp;
+  const int64_t end = n - start > win ? start + win : n;
   if ((double)(end - start) < (double)win * 0.5) { *lufs = -INFINITY; return WAM_OK; }   // :98-100
-  const float* view[2] = { ch[0] + start, nch > 1 ? ch[1] + start : nullptr };
-  return wam_measure_lufs(view, nch, end - start, sample_rate, -14.0, lufs, nullptr, nullptr, nullptr);   // :118, default fallback
+  std::vector<const float*> view(nch);
+  for (int c = 0; c < nch; c++) view[c] = ch[c] + start;
+  return wam_measure_lufs(view.data(), nch, end - start, sample_rate, -14.0, lufs, nullptr, nullptr, nullptr);   // :118, default fallback
 }
 
 int wam_momentary_lufs(const float* const* ch, int nch, int64_t n, double sample_rate, double position, double* lufs) {
   int rc = check_audio(ch, nch, n); if (rc) return rc;
   if (!lufs || !(sample_rate > 0) || !(position >= 0)) { set_error("invalid momentary arguments"); return WAM_ERR_INVALID; }
   const int64_t win = (int64_t)std::floor(sample_rate * 400 / 1000);               // lufs.js:130-133
-  const int64_t start = (int64_t)std::floor(position * sample_rate);
-  const int64_t end = start + win < n ? start + win : n;
+  const double sp = std::floor(position * sample_rate);
+  if (!(sp < (double)n)) { *lufs = -INFINITY; return WAM_OK; }                     // past the end (also keeps the cast below in range): :135-137
+  const int64_t start = (int64_t)sp;
+  const int64_t end = n - start > win ? start + win : n;
   if ((double)(end - start) < (double)win * 0.5) { *lufs = -INFINITY; return WAM_OK; }   // :135-137
   rc = ensure_device(); if (rc) return rc;
   const int64_t len = end - start;
-  const float* view[2] = { ch[0] + start, nch > 1 ? ch[1] + start : nullptr };
+  std::vector<const float*> view(nch);
+  for (int c = 0; c < nch; c++) view[c] = ch[c] + start;
   DevBuf in, sums;
-  rc = upload(view, nch, len, in, nullptr); if (rc) return rc;
-  rc = sums.alloc(sizeof(double) * 2); if (rc) return rc;
+  rc = upload(view.data(), nch, len, in, nullptr); if (rc) return rc;
+  rc = sums.alloc(sizeof(double) * (size_t)nch); if (rc) return rc;
   rc = enqueue_momentary(in.as<float>(), nch, len, sample_rate, sums.as<double>(), nullptr); if (rc) return rc;
-  double hs[2] = {0, 0};
-  WAM_HIP(hipMemcpy(hs, sums.p, sizeof(double) * nch, hipMemcpyDeviceToHost));
+  std::vector<double> hs(nch, 0.0);
+  WAM_HIP(hipMemcpy(hs.data(), sums.p, sizeof(double) * (size_t)nch, hipMemcpyDeviceToHost));
   double ss = 0;
   for (int c = 0; c < nch; c++) ss += hs[c];
   const double ms = ss / ((double)len * nch);                                       // :167
@@ -366,7 +402,7 @@ int wam_lufs_series(const float* const* ch, int nch, int64_t n, double sample_ra
 
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate, double fallback,
                         double* lufs, double* dbtp, void* stream) {
-  if (!in_dev || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
+  if (!in_dev || ntracks < 1 || nch < 1 || nch > kMaxMeterChannels || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
   int rc = ensure_device(); if (rc) return rc;
   return meter_dev(in_dev, ntracks, nch, n, sample_rate, fallback, lufs, dbtp, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }

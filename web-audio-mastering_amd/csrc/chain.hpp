@@ -35,14 +35,28 @@ struct HeavyPlan {             // stages 2-4: exciter.js, multiband-saturation.j
   OnePole p_smooth;
 };
 
+// Progress reporting of one request (sendProgress, dsp-worker.js:69-71): a stage is reported once the stages before it are
+// really done, hence the stream synchronisation.  A non-zero return from the callback cancels the request.
+struct Progress {
+  wam_progress_cb cb; void* user; hipStream_t stream;
+  int operator()(double p, const char* status) const {
+    if (!cb) return WAM_OK;
+    WAM_HIP(hipStreamSynchronize(stream));
+    if (cb(p, status, user)) { set_error("Cancelled"); return WAM_ERR_CANCELLED; }
+    return WAM_OK;
+  }
+};
+
 // ---- launchers (chain_*.hip).  All buffers are device pointers, layout [ntracks][nch][n]. ----
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, double sr, hipStream_t s);
 
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
                       const double* gains_dev, double sr, hipStream_t s);
+// prog (optional): the worker limiter's own progress messages, dsp-worker.js:302,364,427,448
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
-                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s);
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s,
+                    const Progress* prog = nullptr);
 
 int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s);
 int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const HeavyPlan& hp_host, unsigned* winpeak, float* sm, float* env,

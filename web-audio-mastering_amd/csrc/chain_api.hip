@@ -76,7 +76,7 @@ int make_clip_plan(double sr, double ceiling_db, double lookahead_ms, double rel
   p->range = p->ceil_lin - p->thr_lin;                             // soft-clipper.js:203-204
   p->range_div = std::fmax(p->range, 0.001);
   p->drive = drive;
-  if (p->L < 0 || p->L > 256) { set_error("soft-clip lookahead of %d samples is outside 0..256", p->L); return WAM_ERR_INVALID; }
+  if (p->L < 0 || p->L > 1024) { set_error("soft-clip lookahead of %d samples is outside 0..1024", p->L); return WAM_ERR_INVALID; }   // kClipMaxL, chain_tail.hip
   return WAM_OK;
 }
 
@@ -92,8 +92,10 @@ int make_limiter_plan(double sr, double ceil_lin, double lookahead_ms, double re
   p->pa = std::exp(-1 / (0.001 * sr));                             // dsp-worker.js:335-336
   p->pr = std::exp(-1 / (0.050 * sr));
   p->preserve = preserve;
-  if (p->L < 1 || p->L > 1024 || p->W < 1 || p->W > 1024) {
-    set_error("limiter lookahead (%d) / RMS window (%d) outside 1..1024 samples (sample rate %.1f)", p->L, p->W, sr);
+  // The look-ahead window lives in LDS beside one tile (L <= 4096: the slide copies disjoint ranges); the RMS window is a ring
+  // of W prefix sums in LDS (W <= 12,288: 160 KB).  3 ms / 10 ms: sample rates up to 1.2 MHz.
+  if (p->L < 1 || p->L > kTile || p->W < 1 || p->W > 12288) {
+    set_error("limiter lookahead (%d) outside 1..%d or RMS window (%d) outside 1..12288 samples (sample rate %.1f)", p->L, kTile, p->W, sr);
     return WAM_ERR_INVALID;
   }
   return WAM_OK;
@@ -146,16 +148,6 @@ static int run_front_only(const float* const* ch, int nch, int64_t n, double sr,
 
 
 // ---------------------------------------------------------------------------- RENDER_FULL_CHAIN driver
-struct Progress {
-  wam_progress_cb cb; void* user; hipStream_t stream;
-  int operator()(double p, const char* status) const {
-    if (!cb) return WAM_OK;
-    WAM_HIP(hipStreamSynchronize(stream));            // report a stage once the previous ones are really done
-    if (cb(p, status, user)) { set_error("Cancelled"); return WAM_ERR_CANCELLED; }
-    return WAM_OK;
-  }
-};
-
 static double js_number_or_zero(double v) { return (v == v) ? v : 0.0; }   // Number(x) || 0
 
 // One group of tracks, everything device-resident.  dsp-worker.js:1468-1667.
@@ -301,7 +293,7 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
       rc = prog(0.95, "Applying final limiter..."); if (rc) return rc;
       dst = next_dst();
       WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, stream));
-      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, lp.L, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, stream); if (rc) return rc;
+      rc = enqueue_limiter(src, dst, tmb.as<float>(), genv.as<float>(), T, nch, n, lp_d, lp.L, 1, M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, stream, &prog); if (rc) return rc;
       src = dst;
       rc = enqueue_gate(mp, T, M2, stream); if (rc) return rc;
       final_meter = &M2;
@@ -333,6 +325,7 @@ static int render_batch_dev(const float* in, float* out, int T, int nch, int64_t
                             wam_result* results, hipStream_t stream, wam_progress_cb cb, void* user) {
   if (!in || !out || !st || T < 1 || nch < 1 || nch > 2 || n < 0 || !(sr > 0)) { set_error("invalid render arguments"); return WAM_ERR_INVALID; }
   int rc = ensure_device(); if (rc) return rc;
+  const StreamScope scope(stream);
   const Progress prog{cb, user, stream};
   const int group = 256;                              // bounds the scratch: ~2.5 x the group's audio
   for (int t0 = 0; t0 < T; t0 += group) {
@@ -386,7 +379,7 @@ int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double 
 }
 
 static int limiter_entry(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
-                         double knee_db, int preserve_transients, float* const* out, int lib_twin) {
+                         double knee_db, int preserve_transients, float* const* out, int lib_twin, wam_progress_cb cb, void* user) {
   int rc = check_io(ch, nch, n, out); if (rc) return rc;
   if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
   LimiterPlan lp; rc = make_limiter_plan(sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients != 0, &lp); if (rc) return rc;
@@ -396,18 +389,20 @@ static int limiter_entry(const float* const* ch, int nch, int64_t n, double sr, 
   DevBuf plan, genv, tm; rc = upload_plan(lp, plan, nullptr); if (rc) return rc;
   rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
   rc = tm.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
+  const Progress prog{cb, user, nullptr};
   rc = enqueue_limiter(st.in.as<float>(), st.out.as<float>(), tm.as<float>(), genv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L,
-                       preserve_transients != 0, nullptr, nullptr, 0, nullptr, sr, nullptr);
+                       preserve_transients != 0, nullptr, nullptr, 0, nullptr, sr, nullptr, &prog);
   if (rc) return rc;
-  return st.down(st.out.as<float>(), out, nullptr);
+  rc = st.down(st.out.as<float>(), out, nullptr); if (rc) return rc;
+  return prog(1.0, "Complete");                                         // the handler's closing message, dsp-worker.js:1673
 }
 int wam_limiter(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
-                double knee_db, int preserve_transients, float* const* out) {
-  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 0);
+                double knee_db, int preserve_transients, float* const* out, wam_progress_cb progress, void* user) {
+  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 0, progress, user);
 }
 int wam_limiter_lib(const float* const* ch, int nch, int64_t n, double sr, double ceiling_linear, double lookahead_ms, double release_ms,
                     double knee_db, int preserve_transients, float* const* out) {
-  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 1);
+  return limiter_entry(ch, nch, n, sr, ceiling_linear, lookahead_ms, release_ms, knee_db, preserve_transients, out, 1, nullptr, nullptr);
 }
 
 static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int which, float* const* out) {
@@ -490,6 +485,7 @@ int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, do
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(WAM_ERR_HIP); }
     auto body = [&]() -> int {
+      const StreamScope scope(st);
       DevBuf din, dout;
       int r = din.alloc(sizeof(float) * per * group); if (r) return r;
       r = dout.alloc(sizeof(float) * per * group); if (r) return r;

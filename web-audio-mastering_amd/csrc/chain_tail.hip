@@ -13,6 +13,7 @@
 namespace wam {
 
 __device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
+constexpr int kClipMaxL = 1024;                 // soft-clip look-ahead held in LDS: 0.5 ms up to 2 MHz
 
 // exclusive block sum of one double per thread; total returned in `total`.  lds: 4 doubles.
 __device__ __forceinline__ double block_excl_sum(double v, double& total, double* lds) {
@@ -41,7 +42,7 @@ template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ in, int64_t n, const ClipPlan* __restrict__ cp,
                                                      const double* __restrict__ gains, float* __restrict__ g_out,
                                                      int64_t seg_tiles, int64_t warm) {
-  constexpr int kMaxL = 256;
+  constexpr int kMaxL = kClipMaxL;
   __shared__ unsigned gwin[kMaxL + kTile];       // gain bits of [tile_base - L, tile_end)
   __shared__ double rt[kMaxL + 1];               // ramp position m / L  (soft-clipper.js:213-214 with i - start == L)
   __shared__ double lds_scan[kSlotDoubles];
@@ -111,12 +112,10 @@ __global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ i
       else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
     }
     __syncthreads();
-    // slide the window by one tile
-    unsigned keep = one;
-    if (threadIdx.x < L) keep = gwin[kTile + threadIdx.x];
+    // slide the window by one tile: [kTile, kTile + L) -> [0, L) (disjoint, L <= kTile), then the rest back to 1.0
+    for (int i = threadIdx.x; i < L; i += kThreads) gwin[i] = gwin[kTile + i];
     __syncthreads();
     for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = one;
-    if (threadIdx.x < L) gwin[threadIdx.x] = keep;
     __syncthreads();
   }
 }
@@ -195,9 +194,9 @@ __global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
                                                      float* __restrict__ tm_out, int64_t seg_tiles, int64_t warm) {
-  constexpr int kMaxW = 1024;
   __shared__ double pre[kTile + kTile / 16 + 8];       // padded inclusive prefix of the tile's mean squares
-  __shared__ double tail[kMaxW + kMaxW / 16 + 8];      // previous tile's last W prefixes, relative to this tile's origin
+  extern __shared__ double tail[];                     // the last W prefixes before this tile, relative to this tile's origin (padi(W) + 8
+                                                       // doubles of dynamic LDS; W > kTile: a ring, logical index m at (ring + m) mod W)
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ double lds_sum[4];
   const LimiterPlan& P = *lp;
@@ -206,7 +205,8 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   float* tmo = tm_out + trk * n;
   LdsSlots slots(lds_scan);
   double Spk = 0;
-  for (int i = threadIdx.x; i < kMaxW + kMaxW / 16 + 8; i += kThreads) tail[i] = 0;
+  int ring = 0;                                        // stays 0 while W <= kTile
+  for (int i = threadIdx.x; i < padi(W) + 8; i += kThreads) tail[i] = 0;
   __syncthreads();
   // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact after W <= 1024 samples
   // and the peak follower forgets as exp(-k / (50 ms))
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
       const int j = threadIdx.x * C + k;
       const int64_t i = base + k;
       const double hi = off + q[k];
-      const double lo = (j - W >= 0) ? pre[padi(j - W)] : tail[padi(j)];
+      int jr = ring + j; if (jr >= W) jr -= W;                                   // (j < W here whenever the ring has turned)
+      const double lo = (j - W >= 0) ? pre[padi(j - W)] : tail[padi(jr)];
       const int64_t ws = i + 1 < W ? i + 1 : W;
       const float rms = f32r(sqrt((hi - lo) / (double)ws));
       const float pke = f32r(e);
@@ -257,13 +258,19 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
     }
     if (t >= T0) store_chunk(tmo, n, base, tmv);
     __syncthreads();
-    // next tile's tail = this tile's last W prefixes minus this tile's total
-    double keep[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; keep[r] = (m < W) ? pre[padi(kTile - W + m)] - total : 0.0; }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; if (m < W) tail[padi(m)] = keep[r]; }
+    // next tile's tail = the last W prefixes, re-based to the next tile's origin (minus this tile's total): from this tile
+    // alone when W <= kTile; else the ring turns by one tile, its newest kTile entries come from this tile and the older
+    // ones are re-based in place.  (All reads of tail for this tile lie before the barrier above.)
+    if (W <= kTile) {
+      for (int m = threadIdx.x; m < W; m += kThreads) tail[padi(m)] = pre[padi(kTile - W + m)] - total;
+    } else {
+      ring += kTile; if (ring >= W) ring -= W;
+      for (int m = threadIdx.x; m < W; m += kThreads) {
+        int ph = ring + m; if (ph >= W) ph -= W;
+        if (m >= W - kTile) tail[padi(ph)] = pre[padi(kTile - W + m)] - total;
+        else tail[padi(ph)] -= total;
+      }
+    }
     __syncthreads();
   }
 }
@@ -272,8 +279,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__ in, int64_t n, const LimiterPlan* __restrict__ lp,
                                                        const float* __restrict__ tm, float* __restrict__ g_out, int64_t seg_tiles, int64_t warm) {
-  constexpr int kMaxL = 1024;
-  __shared__ float gwin_s[kMaxL + kTile];       // gain envelope of [tile_base - L, tile_end)
+  extern __shared__ float gwin_s[];             // gain envelope of [tile_base - L, tile_end): L + kTile floats of dynamic LDS
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[NCH][kCtxFloats];
   volatile float* gwin = gwin_s;
@@ -374,13 +380,9 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
       else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
     }
     __syncthreads();
-    // slide the window by one tile
-    float keep[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; keep[r] = (m < L) ? gwin[kTile + m] : 1.0f; }
+    // slide the window by one tile: [kTile, kTile + L) -> [0, L) (disjoint, L <= kTile), then the rest back to 1.0
+    for (int i = threadIdx.x; i < L; i += kThreads) gwin[i] = gwin[kTile + i];
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int m = threadIdx.x + r * kThreads; if (m < L) gwin[m] = keep[r]; }
     for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = 1.0f;
     __syncthreads();
   }
@@ -465,6 +467,14 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------- launchers
+// A kernel whose static + dynamic LDS exceeds the 64 KB default must be opted in (gfx950 has 160 KB per workgroup).
+static int lds_opt_in(const void* kernel, size_t dynamic_bytes, size_t static_bytes) {
+  if (dynamic_bytes + static_bytes <= 64 * 1024) return WAM_OK;
+  if (dynamic_bytes + static_bytes > 160 * 1024) { set_error("window of %zu bytes does not fit the 160 KB of LDS", dynamic_bytes); return WAM_ERR_TOO_LARGE; }
+  WAM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes));
+  return WAM_OK;
+}
+
 int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
                       const double* gains_dev, double sr, hipStream_t s) {
   if (n <= 0) return WAM_OK;
@@ -481,24 +491,48 @@ int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int
 }
 
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
-                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s) {
-  if (n <= 0) return WAM_OK;
+                    int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s,
+                    const Progress* prog) {
+  // the worker limiter's own messages (dsp-worker.js:302,364,427,448), at the points where its stages start; the per-channel
+  // messages follow the kernel that processes all channels at once
+  auto say = [&](double p, const char* status) -> int { return prog ? (*prog)(p, status) : WAM_OK; };
+  int prc = say(0.1, "Analyzing transients..."); if (prc) return prc;
+  if (n <= 0) {
+    if ((prc = say(0.3, "Calculating gain envelope..."))) return prc;
+    if ((prc = say(0.6, "Applying limiting..."))) return prc;
+    for (int c = 0; c < nch; c++) {
+      char msg[64]; snprintf(msg, sizeof(msg), "Processing channel %d/%d...", c + 1, nch);
+      if ((prc = say(0.6 + 0.3 * ((double)(c + 1) / nch), msg))) return prc;
+    }
+    return WAM_OK;
+  }
   const int64_t warm = scale_warm(tuning().lim_warm_tiles, sr);
   const int64_t seg = pick_segment_tiles(ntracks, (n + L + kTile - 1) / kTile, warm, tuning().env_seg_tiles);
   if (preserve) {
     const unsigned nseg = (unsigned)(((n + kTile - 1) / kTile + seg - 1) / seg);
-    if (nch == 2) WAM_LAUNCH("k_lim_tm", k_lim_tm<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, tm, seg, warm);
-    else WAM_LAUNCH("k_lim_tm", k_lim_tm<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, tm, seg, warm);
+    const int W = (int)std::floor(sr * 10 / 1000);                    // = LimiterPlan::W (dsp-worker.js:308-309)
+    const size_t tail_bytes = sizeof(double) * (size_t)(W + (W >> 4) + 8);
+    int rc = lds_opt_in((const void*)(nch == 2 ? k_lim_tm<2> : k_lim_tm<1>), tail_bytes, sizeof(double) * (kTile + kTile / 16 + 8 + kSlotDoubles + 4));
+    if (rc) return rc;
+    if (nch == 2) WAM_LAUNCH_SHMEM("k_lim_tm", k_lim_tm<2>, dim3(nseg, ntracks), dim3(kThreads), tail_bytes, s, in, n, plan_dev, tm, seg, warm);
+    else WAM_LAUNCH_SHMEM("k_lim_tm", k_lim_tm<1>, dim3(nseg, ntracks), dim3(kThreads), tail_bytes, s, in, n, plan_dev, tm, seg, warm);
   }
+  if ((prc = say(0.3, "Calculating gain envelope..."))) return prc;
   const float* tmi = preserve ? tm : nullptr;
   const unsigned nsegg = (unsigned)(((n + L + kTile - 1) / kTile + seg - 1) / seg);
-  if (nch == 2) WAM_LAUNCH("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
-  else WAM_LAUNCH("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), s, in, n, plan_dev, tmi, genv, seg, warm);
+  const size_t gwin_bytes = sizeof(float) * (size_t)(L + kTile);
+  if (nch == 2) WAM_LAUNCH_SHMEM("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), gwin_bytes, s, in, n, plan_dev, tmi, genv, seg, warm);
+  else WAM_LAUNCH_SHMEM("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), gwin_bytes, s, in, n, plan_dev, tmi, genv, seg, warm);
+  if ((prc = say(0.6, "Applying limiting..."))) return prc;
   {
     const int64_t ntiles = (n + kTile - 1) / kTile, mwarm = meter_warm((int64_t)std::floor(sr * 0.1), sr);
     const int64_t mseg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, mwarm, tuning().meter_seg_tiles);
     WAM_LAUNCH("k_lim_apply", k_lim_apply, dim3(ntracks * nch, (unsigned)((ntiles + mseg - 1) / mseg)), dim3(kThreads), s, in, out, nch, n, plan_dev,
                (const float*)genv, meter_dev, hopsums, hop_stride, peaks, mseg, mwarm);
+  }
+  for (int c = 0; c < nch; c++) {
+    char msg[64]; snprintf(msg, sizeof(msg), "Processing channel %d/%d...", c + 1, nch);
+    if ((prc = say(0.6 + 0.3 * ((double)(c + 1) / nch), msg))) return prc;
   }
   return WAM_OK;
 }

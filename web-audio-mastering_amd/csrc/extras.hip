@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in,
   }
 }
 
-static int check_in(const float* const* ch, int nch, int64_t n) {
-  if (!ch || nch < 1 || nch > 2 || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
+static int check_in(const float* const* ch, int nch, int64_t n, int max_nch = 2) {
+  if (!ch || nch < 1 || nch > max_nch || n < 0) { set_error("invalid audio arguments (nch=%d, n=%lld)", nch, (long long)n); return WAM_ERR_INVALID; }
   for (int c = 0; c < nch; c++) if (!ch[c] && n > 0) { set_error("channel %d is NULL", c); return WAM_ERR_INVALID; }
   return WAM_OK;
 }
@@ -383,7 +383,7 @@ using namespace wam;
 extern "C" {
 
 int wam_dc_offset(const float* const* ch, int nch, int64_t n, double* dc, int remove, float* const* out) {
-  int rc = check_in(ch, nch, n); if (rc) return rc;
+  int rc = check_in(ch, nch, n, 64); if (rc) return rc;               // detectDCOffsetBuffer loops over numberOfChannels (dc-offset.js:38-60)
   if (!dc || (remove && !out)) { set_error("dc / out is NULL"); return WAM_ERR_INVALID; }
   rc = ensure_device(); if (rc) return rc;
   if (n == 0) { for (int c = 0; c < nch; c++) dc[c] = NAN; return WAM_OK; }     // 0 / 0 in the reference
@@ -457,11 +457,13 @@ int wam_extract_peaks(const float* ch0, int64_t n, int num_peaks, float* peaks) 
 }
 
 int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double target_lufs, double ceiling_db, float* const* out,
-                  wam_normalize_result* res) {
+                  wam_normalize_result* res, wam_progress_cb progress, void* user) {
   int rc = check_in(ch, nch, n); if (rc) return rc;
   if (!out || !res || !(sr > 0)) { set_error("invalid normalize arguments"); return WAM_ERR_INVALID; }
   rc = ensure_device(); if (rc) return rc;
   std::memset(res, 0, sizeof(*res));
+  const Progress prog{progress, user, nullptr};
+  rc = prog(0.05, "Measuring loudness..."); if (rc) return rc;                                 // dsp-worker.js:458
   MeterPlan mp; rc = make_meter_plan(nch, n, sr, target_lufs, &mp); if (rc) return rc;      // measure with fallback = target (:460)
   MeterPlan mp14 = mp; mp14.fallback = -14.0;                                                 // final measurements use the default (:504,:517)
   DevBuf in, tmp, o, ms, ms2, gd;
@@ -477,9 +479,10 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
   if (!std::isfinite(cur)) {                                                                  // :466-469
     for (int c = 0; c < nch && n > 0; c++) std::memcpy(out[c], ch[c], sizeof(float) * (size_t)n);
     res->final_lufs = cur; res->peak_db = pk; res->measured = 0;
-    return WAM_OK;
+    return prog(1.0, "Complete");                                                             // the handler's closing message, :1673
   }
   res->measured = 1;
+  rc = prog(0.15, "Applying gain..."); if (rc) return rc;                                     // :471
   const double gdb = target_lufs - cur;                                                       // :473-476
   const double gl = std::pow(10, gdb / 20);
   const double proj = pk + gdb;
@@ -492,6 +495,7 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
   WAM_HIP(hipMemcpyAsync(M2.plan, &mp14, sizeof(mp14), hipMemcpyHostToDevice, nullptr));
   const float* result = tmp.as<float>();
   if (proj > ceiling_db) {                                                                    // :490-515
+    rc = prog(0.25, "Applying limiter..."); if (rc) return rc;                                // :491
     LimiterPlan lp; rc = make_limiter_plan(sr, std::pow(10, ceiling_db / 20), 3, 100, 3, 1, &lp); if (rc) return rc;
     DevBuf plan, tmb, gv;
     rc = plan.alloc(sizeof(lp)); if (rc) return rc;
@@ -502,7 +506,7 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
     rc = enqueue_gain_meter(in.as<float>(), tmp.as<float>(), 1, nch, n, gd.as<double>(), mp14, M2, nullptr); if (rc) return rc;
     WAM_HIP(hipMemsetAsync(M2.hopsums, 0, M2.hopsums_bytes, nullptr));
     rc = enqueue_limiter(tmp.as<float>(), o.as<float>(), tmb.as<float>(), gv.as<float>(), 1, nch, n, plan.as<LimiterPlan>(), lp.L, 1,
-                         M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, nullptr); if (rc) return rc;
+                         M2.plan, M2.hopsums, M2.hop_stride, M2.peaks, sr, nullptr, &prog); if (rc) return rc;
     rc = enqueue_gate(mp14, 1, M2, nullptr); if (rc) return rc;
     WAM_HIP(hipMemcpy(&g, M2.gate, sizeof(g), hipMemcpyDeviceToHost));
     res->peak_db = finish_peak_db(g);
@@ -510,14 +514,14 @@ int wam_normalize(const float* const* ch, int nch, int64_t n, double sr, double 
     res->limiter_applied = 1;
     result = o.as<float>();
     for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpy(out[c], result + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
-    return WAM_OK;
+    return prog(1.0, "Complete");
   }
   rc = enqueue_gain_meter(in.as<float>(), tmp.as<float>(), 1, nch, n, gd.as<double>(), mp14, M2, nullptr); if (rc) return rc;
   WAM_HIP(hipMemcpy(&g, M2.gate, sizeof(g), hipMemcpyDeviceToHost));
   res->final_lufs = finish_lufs(mp14, g);
   res->peak_db = proj;
   for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpy(out[c], result + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
-  return WAM_OK;
+  return prog(1.0, "Complete");
 }
 
 // The analysis the app runs on every file load (web/app.js:823-872), as one call with one upload: DC detection
@@ -684,6 +688,7 @@ int64_t wam_stft_num_frames(int64_t n, int nfft, int hop) {
 static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, double sr, int nfft, int hop, float* out_db_dev, float* cols_dev,
                         hipStream_t stream) {
   using namespace wam;
+  const StreamScope scope(stream);
   const int64_t nframes = wam_stft_num_frames(n, nfft, hop);
   if (nframes == 0 || ntracks == 0) return WAM_OK;
   int bits = 0; while ((1 << bits) < nfft) bits++;
@@ -718,7 +723,7 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
   if (ntracks >= 64 && bx > 128) bx = 128;                               // enough workgroups from the track dimension
   const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
   const float* ct = tabs.as<float>(); const float* st = ct + nfft; const float* wn = ct + 2 * nfft;
-  prof_begin("k_stft", stream);
+  const int prof_ticket = prof_begin("k_stft", stream);
   if (nfft == 4096 && !tuning().stft_literal)
     hipLaunchKernelGGL(k_stft_fast<12>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
                        out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
@@ -728,7 +733,7 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
   else
     hipLaunchKernelGGL(k_stft, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), shmem, stream, in_dev, nch, n, nfft, bits, hop, nframes, ct, st, wn,
                        add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
-  prof_end(stream);
+  prof_end(prof_ticket, stream);
   WAM_HIP(hipGetLastError());
   WAM_HIP(hipStreamSynchronize(stream));                                 // tables (host vectors, pool blocks) are released on return
   return WAM_OK;

@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void k_gate(const double* __restrict__ hopsums
     double ss = 0;
     for (int c = 0; c < nch; c++) {
       const double* hs = hopsums + (trk * nch + c) * hop_stride;
-      ss += ((hs[b] + hs[b + 1]) + hs[b + 2]) + hs[b + 3];
+      double sc = ((hs[b] + hs[b + 1]) + hs[b + 2]) + hs[b + 3];
+      for (int j = 0; j < pl.rem; j++) sc += hs[pl.heads_off + 4 * (b + 4) + j];      // block = 4 hops + rem samples of the fifth
+      ss += sc;
     }
     bl[b] = ss / denom;
   }
@@ -215,12 +217,15 @@ int make_meter_plan(int nch, int64_t n, double sr, double fallback, MeterPlan* p
   pl->nch = nch;
   pl->fallback = fallback;
   pl->too_short = ((double)n / sr < 0.4) ? 1 : 0;                    // lufs.js:23
-  if (pl->hop < C || pl->block != 4 * pl->hop) {
-    set_error("sample rate %.3f Hz: the 400 ms block (%lld) is not four 100 ms hops (%lld); unsupported", sr,
-              (long long)pl->block, (long long)pl->hop);
+  const int64_t rem = pl->block - 4 * pl->hop;                       // 0..3 by construction (floor of a value and of its quarter)
+  if (pl->hop < C || rem < 0 || rem > 3) {
+    set_error("sample rate %.3f Hz: a 100 ms hop of %lld samples (block %lld) is outside what the meter kernels take (hop >= %d)", sr,
+              (long long)pl->hop, (long long)pl->block, C);
     return WAM_ERR_INVALID;
   }
+  pl->rem = (int)rem;
   pl->nhops = n / pl->hop;
+  pl->heads_off = pl->nhops + 4;
   pl->nblocks = 0;
   for (int64_t st = 0; st + pl->block <= n; st += pl->hop) pl->nblocks++;
   return WAM_OK;
@@ -233,8 +238,11 @@ double finish_lufs(const MeterPlan& pl, const GateOut& g) {
 }
 double finish_peak_db(const GateOut& g) { return g.peak > 0 ? 20 * std::log10(g.peak) : -INFINITY; }   // true-peak.js:70
 
+// one channel's row: hop sums [nhops + 4], then (rem > 0) the hop heads [4 (nhops + 2)]
+static int64_t meter_hop_stride(const MeterPlan& pl) { return pl.nhops + 4 + (pl.rem > 0 ? 4 * (pl.nhops + 2) : 0); }
+
 size_t meter_scratch_bytes(const MeterPlan& pl, int ntracks, bool want_mask) {
-  const int64_t hs = pl.nhops + 4;
+  const int64_t hs = meter_hop_stride(pl);
   size_t b = 0;
   b += align_up(sizeof(MeterPlan), 256);
   b += align_up(sizeof(double) * (size_t)hs * ntracks * pl.nch, 256);
@@ -247,7 +255,7 @@ size_t meter_scratch_bytes(const MeterPlan& pl, int ntracks, bool want_mask) {
 
 void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void* scratch, MeterScratch* s) {
   char* p = (char*)scratch;
-  s->hop_stride = pl.nhops + 4;
+  s->hop_stride = meter_hop_stride(pl);
   s->plan = (MeterPlan*)p; p += align_up(sizeof(MeterPlan), 256);
   const size_t hs_bytes = sizeof(double) * (size_t)s->hop_stride * ntracks * pl.nch;
   s->hopsums = (double*)p; p += align_up(hs_bytes, 256);

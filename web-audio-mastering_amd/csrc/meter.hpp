@@ -17,7 +17,9 @@ struct MeterPlan {
   int64_t hop;        // samples per 100 ms hop
   int64_t nhops;      // complete hops in the track
   int64_t nblocks;    // 400 ms blocks
-  int64_t block;      // samples per block (= 4 * hop, checked on the host)
+  int64_t block;      // samples per block: 4 hops + `rem` samples (rem = 0 at the usual rates; 11,025 Hz: 4410 = 4 * 1102 + 2)
+  int64_t heads_off;  // rem > 0: offset, inside a channel's hop-sum row, of the "hop heads": z^2 of the first `rem` samples of every hop, 4 slots per hop
+  int rem;            // block - 4 * hop, 0..3 (lufs.js:53-54: block = floor(0.4 sr), hop = floor(0.4 sr * 0.25))
   int nch;
   double fallback;
   int too_short;      // duration < 0.4 s -> lufs = fallback (lufs.js:23-26)
@@ -28,7 +30,7 @@ struct MeterPlan {
 // hop that lies in its warm-up tiles: every hop sum is accumulated by one workgroup, in tile order - deterministic,
 // no atomics.  (Needs warm >= 2 tiles + the settle time of whatever feeds the meter: a hop is 1.17 tiles.)
 struct Segment {
-  int64_t T0, T1, Tw, own_from, hop_lo, hop_hi;
+  int64_t T0, T1, Tw, own_from, own_to, hop_lo, hop_hi;
 };
 __device__ __forceinline__ Segment make_segment(int64_t seg_idx, int64_t seg_tiles, int64_t warm, int64_t ntiles, int64_t hop, int64_t nhops) {
   Segment g;
@@ -36,6 +38,7 @@ __device__ __forceinline__ Segment make_segment(int64_t seg_idx, int64_t seg_til
   g.T1 = g.T0 + seg_tiles; if (g.T1 > ntiles) g.T1 = ntiles;
   g.Tw = g.T0 - warm > 0 ? g.T0 - warm : 0;
   g.own_from = g.T0 * kTile;
+  g.own_to = g.T1 * kTile;
   g.hop_lo = hop > 0 ? g.own_from / hop : 0;
   g.hop_hi = (g.T1 >= ntiles || hop <= 0) ? nhops : (g.T1 * kTile) / hop;
   if (g.hop_hi > nhops) g.hop_hi = nhops;
@@ -64,9 +67,9 @@ __device__ __forceinline__ void meter_peak_part(const float x[C], const float xp
 
 // ---- per-hop sums of squares of the K-weighted chunk v[] (double values that are about to be rounded to f32)
 template <class St>
-__device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, int64_t tile_base, const MeterPlan& pl, St& m,
+__device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, int64_t tile_base, int64_t n, const MeterPlan& pl, St& m,
                                                double* lds, double* hopsums) {
-  const int64_t lim = pl.nhops * pl.hop;       // samples past the last complete hop never reach a block
+  const int64_t lim = pl.nhops * pl.hop;       // samples past the last complete hop never reach a block through a hop sum
   double sA = 0, sB = 0;
   const int64_t to_boundary = pl.hop - m.hop_off;   // samples of this chunk that belong to hop_idx
 #pragma unroll
@@ -74,6 +77,19 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
     const double z = (double)f32r(v[k]);
     const double zz = (base + k < lim) ? z * z : 0.0;
     if (k < to_boundary) sA += zz; else sB += zz;
+  }
+  if (pl.rem > 0) {
+    // A block that is `rem` samples longer than four hops ends with the first `rem` samples of a fifth hop (lufs.js:57-65 sums
+    // sample ranges): those squares are kept one by one, 4 slots per hop, each written by the one workgroup that owns the sample
+    // (its own tiles, not its warm-up), so the gate kernel adds them in a fixed order.
+    double* heads = hopsums + pl.heads_off;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      int64_t pos = m.hop_off + k, h = m.hop_idx;
+      if (pos >= pl.hop) { pos -= pl.hop; h++; }
+      const int64_t i = base + k;
+      if (pos < pl.rem && i < n && i >= m.own_from && i < m.own_to) { const double z = (double)f32r(v[k]); heads[4 * h + pos] = z * z; }
+    }
   }
   int64_t h_first = tile_base / pl.hop;
   int64_t last = tile_base + kTile - 1; if (last > lim - 1) last = lim - 1;
@@ -112,7 +128,7 @@ struct MeterStateL {            // carried across tiles, per channel
   const double* P1; const double* P2; double* S1; double* S2;   // lane powers / tile carries of the two filters (LDS)
   double peak;                 // running true peak of this thread
   int64_t hop_idx, hop_off;    // hop index / offset of this thread's chunk start
-  int64_t own_from;            // time segments: first sample whose peak this workgroup reports ...
+  int64_t own_from, own_to;    // time segments: the samples [own_from, own_to) whose peaks (and hop heads) this workgroup reports ...
   int64_t hop_lo, hop_hi;      // ... and the hops [hop_lo, hop_hi) it accumulates (each hop has exactly one owner)
 };
 __device__ __forceinline__ void meter_init_l(MeterStateL& m, const MeterPlan& pl, int64_t first_sample, const Segment& seg,
@@ -121,7 +137,7 @@ __device__ __forceinline__ void meter_init_l(MeterStateL& m, const MeterPlan& pl
   if (threadIdx.x < 2) { S1[threadIdx.x] = 0; S2[threadIdx.x] = 0; }
   m.P1 = P1; m.P2 = P2; m.S1 = S1; m.S2 = S2;
   m.peak = 0;
-  m.own_from = seg.own_from; m.hop_lo = seg.hop_lo; m.hop_hi = seg.hop_hi;
+  m.own_from = seg.own_from; m.own_to = seg.own_to; m.hop_lo = seg.hop_lo; m.hop_hi = seg.hop_hi;
   const int64_t b = first_sample + (int64_t)threadIdx.x * C;
   m.hop_idx = b / pl.hop;
   m.hop_off = b - m.hop_idx * pl.hop;
@@ -138,7 +154,7 @@ __device__ __forceinline__ void meter_chunk_l(const float x[C], const float xp[3
   for (int k = 0; k < C; k++) v[k] = (double)f32r(v[k]);
   double t0, t1;
   biquad_chunk_lds(v, (double)f32r(s0), (double)f32r(s1), pl.hp, m.P2, m.S2, lds + 8, t0, t1);
-  meter_hop_part(v, base, tile_base, pl, m, lds, hopsums);
+  meter_hop_part(v, base, tile_base, n, pl, m, lds, hopsums);
 }
 
 // Two channels of one track in lock-step: the K-weighting stages as fused pairs (one barrier per stage for both channels).
@@ -158,8 +174,8 @@ __device__ __forceinline__ void meter_chunk_l2(const float xa[C], const float xp
   for (int k = 0; k < C; k++) { va[k] = (double)f32r(va[k]); vb[k] = (double)f32r(vb[k]); }
   biquad_pair_lds(va, (double)f32r(a0), (double)f32r(a1), pl.hp, ma.P2, ma.S2,
                   vb, (double)f32r(b0), (double)f32r(b1), pl.hp, mb.P2, mb.S2, ldsb, c0, c1, d0, d1);
-  meter_hop_part(va, base, tile_base, pl, ma, ldsa, hsa);
-  meter_hop_part(vb, base, tile_base, pl, mb, ldsb, hsb);
+  meter_hop_part(va, base, tile_base, n, pl, ma, ldsa, hsa);
+  meter_hop_part(vb, base, tile_base, n, pl, mb, ldsb, hsb);
 }
 
 // Workgroup-wide final peak, max-ed into peaks[0] (zeroed before the launch; segments of one channel share it).

@@ -25,10 +25,22 @@ int ensure_device();                       // 0 or WAM_ERR_NO_DEVICE; binds the 
 
 // Workspace pool (api.hip): device blocks are kept per device after use and handed out again, because a render group
 // needs tens of GB of intermediates and hipMalloc / hipFree of that size costs more than the kernels that use it.
-// Every entry point synchronises its stream before its DevBufs go out of scope, so a block is idle when it returns
-// to the pool.  wam_trim_workspace() (include/wam_synth.h) gives the memory back to the driver.
+// A block returns to the pool when its DevBuf goes out of scope.  On the success path every entry point has synchronised
+// its stream by then; on an error path kernels that use the block may still be queued, so pool_free records an event on the
+// calling thread's current stream (StreamScope below; the null stream unless an entry point says otherwise) and pool_alloc
+// waits for that event before it hands the block to its next owner.  wam_trim_workspace() (include/wam_synth.h) gives the
+// memory back to the driver.
 void* pool_alloc(size_t bytes, size_t* granted);
 void pool_free(void* p, size_t granted);
+// Names the stream an entry point enqueues on, for the pool's idle events; nests (restores the previous stream).
+struct StreamScope {
+  explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+ private:
+  hipStream_t prev_;
+};
 
 // RAII device buffer
 struct DevBuf {
@@ -49,15 +61,16 @@ struct DevBuf {
 };
 
 // per-kernel timing hooks (include/wam_synth.h: wam_profile_enable / wam_profile_read)
-void prof_begin(const char* name, hipStream_t s);
-void prof_end(hipStream_t s);
-#define WAM_LAUNCH(name, kern, grid, block, stream, ...)                 \
+int prof_begin(const char* name, hipStream_t s);        // returns a ticket for prof_end (-1 when profiling is off)
+void prof_end(int ticket, hipStream_t s);
+#define WAM_LAUNCH_SHMEM(name, kern, grid, block, shmem, stream, ...)    \
   do {                                                                   \
-    ::wam::prof_begin(name, stream);                                     \
-    hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);       \
-    ::wam::prof_end(stream);                                             \
+    const int prof_ticket_ = ::wam::prof_begin(name, stream);            \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);   \
+    ::wam::prof_end(prof_ticket_, stream);                               \
     WAM_HIP(hipGetLastError());                                          \
   } while (0)
+#define WAM_LAUNCH(name, kern, grid, block, stream, ...) WAM_LAUNCH_SHMEM(name, kern, grid, block, 0, stream, __VA_ARGS__)
 
 // Time-segmentation knobs (include/wam_synth.h: wam_tune).  Defaults are the production values; tests shrink them so
 // that short fixtures cross segment seams.
@@ -78,7 +91,7 @@ struct Tuning {
   int64_t stft_literal = 0;       // 1 = always use the stage-by-stage STFT kernel (the register-blocked one must equal it bit for bit)
   int64_t glue_warm_tiles = 50;   // glue follower, 250 ms release (+2 for the straddling hop)
 };
-Tuning& tuning();
+Tuning tuning();          // a snapshot (wam_tune is a test / tuning hook: a request that overlaps a wam_tune call may see either value per kernel)
 
 // Warm-up lengths are stated in tiles at 48 kHz; time constants are in seconds, so they grow with the sample rate.
 inline int64_t scale_warm(int64_t tiles48k, double sr) {

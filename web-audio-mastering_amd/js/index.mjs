@@ -84,7 +84,7 @@ export function analyzeOnLoad(decodedBuffer, targetLufs = -14, ceilingDB = -1) {
     normalizedBuffer: r.measured ? makeAB(r.normalized, sr) : originalBuffer, gainApplied: r.gainDb, limiterApplied: !!r.limiterApplied };
 }
 export function findTruePeak(audioBuffer) {                                          // true-peak.js:46
-  return addon().meterSync(chansOf(audioBuffer), audioBuffer.sampleRate || 48000, -14).peakDB;
+  return addon().meterSync(chansOf(audioBuffer), 48000, -14).peakDB;   // the peak does not depend on the rate (findTruePeakFromChannels takes none)
 }
 export function applyGain(audioBuffer, gainDB) { return stage('gain', audioBuffer, [gainDB]); }   // normalizer.js:103
 export function normalizeToLUFS(audioBuffer, targetLUFS = -14, ceilingDB = -1, options = {}) {    // normalizer.js:38
@@ -199,10 +199,15 @@ export class WamWorker {
         switch (type) {
           case 'MEASURE_LUFS': result = { lufs: (await addon().meter(data.channels, data.sampleRate, -14)).lufs }; break;
           case 'FIND_TRUE_PEAK': result = { peakDB: (await addon().meter(data.channels, 48000, -14)).peakDB }; break;
-          case 'NORMALIZE': result = await addon().normalize(data.channels, data.sampleRate, data.targetLUFS, data.ceilingDB); break;
+          // (the addon's own closing 1.0 'Complete' is dropped: the handler sends it once, below, like dsp-worker.js:1673)
+          case 'NORMALIZE':                                       // targetLUFS / ceilingDB default like the worker function's parameters (:457)
+            result = await addon().normalize(data.channels, data.sampleRate, data.targetLUFS === undefined ? -14 : data.targetLUFS,
+              data.ceilingDB === undefined ? -1 : data.ceilingDB, (p, s) => { if (p < 1) progress(p, s); });
+            break;
           case 'APPLY_LIMITER':
             result = { channels: await addon().stage('limiter', data.channels, data.sampleRate,
-              [data.ceilingLinear || 0.891, data.lookaheadMs || 3, data.releaseMs || 100, data.kneeDB || 3, data.preserveTransients !== false ? 1 : 0]) };
+              [data.ceilingLinear || 0.891, data.lookaheadMs || 3, data.releaseMs || 100, data.kneeDB || 3, data.preserveTransients !== false ? 1 : 0],
+              (p, s) => { if (p < 1) progress(p, s); }) };
             break;
           case 'RENDER_FULL_CHAIN': {
             const r = await addon().renderChain(data.channels, data.sampleRate, data.settings, data.mode, (p, s) => { if (p < 1) progress(p, s); });
@@ -247,14 +252,13 @@ export class DSPWorkerInterface {
     return { lufs: r.lufs };
   }
   async findTruePeak(audioBuffer) {                                                  // :178
-    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
-    const r = await this._send(() => addon().meter(ch, sr, -14));
+    const ch = chansOf(audioBuffer);
+    const r = await this._send(() => addon().meter(ch, 48000, -14));      // rate-independent, dsp-worker.js:1361-1363
     return { peakDB: r.peakDB };
   }
   async normalize(audioBuffer, targetLUFS = -14, ceilingDB = -1, onProgress = null) {   // :197
     const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
-    const r = await this._send(() => addon().normalize(ch, sr, targetLUFS, ceilingDB));
-    if (onProgress) onProgress(1.0, 'Complete');
+    const r = await this._send(() => addon().normalize(ch, sr, targetLUFS, ceilingDB, onProgress || undefined));
     return { audioBuffer: makeAB(r.channels, sr), currentLUFS: r.currentLUFS, finalLUFS: r.finalLUFS, peakDB: r.peakDB,
       gainApplied: r.gainApplied, limiterApplied: r.limiterApplied };
   }
@@ -262,8 +266,7 @@ export class DSPWorkerInterface {
     const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
     const p = [options.ceilingLinear || 0.891, options.lookaheadMs || 3, options.releaseMs || 100, options.kneeDB || 3,
       options.preserveTransients !== false ? 1 : 0];
-    const out = await this._send(() => addon().stage('limiter', ch, sr, p));
-    if (onProgress) onProgress(1.0, 'Complete');
+    const out = await this._send(() => addon().stage('limiter', ch, sr, p, onProgress || undefined));
     return { audioBuffer: makeAB(out, sr) };
   }
   async renderFullChain(audioBuffer, settings, mode = 'preview', onProgress = null) {  // :259

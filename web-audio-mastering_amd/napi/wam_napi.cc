@@ -34,11 +34,12 @@ struct Audio {                       // owned copy of the caller's channels
   std::vector<const float*> ptrs() const { std::vector<const float*> p; for (auto& c : ch) p.push_back(c.data()); return p; }
 };
 
-bool get_audio(napi_env env, napi_value arr, Audio* a) {
+// max_ch: 2 for the rendering stages; the meters and the DC detector take any channel count, like the reference's loops
+bool get_audio(napi_env env, napi_value arr, Audio* a, uint32_t max_ch = 2) {
   bool is_arr = false;
   if (napi_is_array(env, arr, &is_arr) != napi_ok || !is_arr) { napi_throw_type_error(env, nullptr, "channels must be an array of Float32Array"); return false; }
   uint32_t len = 0; napi_get_array_length(env, arr, &len);
-  if (len < 1 || len > 2) { napi_throw_range_error(env, nullptr, "1 or 2 channels supported"); return false; }
+  if (len < 1 || len > max_ch) { napi_throw_range_error(env, nullptr, max_ch == 2 ? "1 or 2 channels supported" : "1 to 64 channels supported"); return false; }
   for (uint32_t i = 0; i < len; i++) {
     napi_value v; napi_get_element(env, arr, i, &v);
     bool is_ta = false; napi_is_typedarray(env, v, &is_ta);
@@ -164,7 +165,7 @@ napi_value start_async(napi_env env, Job* j, napi_value progress_cb) {
 // ---- job builders --------------------------------------------------------------------
 Job* job_meter(napi_env env, napi_value* a) {       // (channels, sampleRate, fallback)
   auto j = std::make_unique<Job>();
-  if (!get_audio(env, a[0], &j->in)) return nullptr;
+  if (!get_audio(env, a[0], &j->in, 64)) return nullptr;
   napi_get_value_double(env, a[1], &j->d[0]);
   j->d[1] = -14; napi_valuetype t; napi_typeof(env, a[2], &t); if (t == napi_number) napi_get_value_double(env, a[2], &j->d[1]);
   j->work = [](Job& j) { auto p = j.in.ptrs(); return wam_meter(p.data(), (int)p.size(), j.in.n, j.d[0], j.d[1], &j.d[2], &j.d[3]); };
@@ -173,7 +174,7 @@ Job* job_meter(napi_env env, napi_value* a) {       // (channels, sampleRate, fa
 }
 Job* job_window_lufs(napi_env env, napi_value* a) {   // (channels, sampleRate, position, momentary) -> number
   auto j = std::make_unique<Job>();
-  if (!get_audio(env, a[0], &j->in)) return nullptr;
+  if (!get_audio(env, a[0], &j->in, 64)) return nullptr;
   napi_get_value_double(env, a[1], &j->d[0]);
   j->d[1] = 0; napi_valuetype t; napi_typeof(env, a[2], &t); if (t == napi_number) napi_get_value_double(env, a[2], &j->d[1]);
   bool mom = false; napi_value b; if (napi_coerce_to_bool(env, a[3], &b) == napi_ok) napi_get_value_bool(env, b, &mom);
@@ -208,13 +209,13 @@ Job* job_render(napi_env env, napi_value* a, bool with_progress) {   // (channel
   };
   return j.release();
 }
-Job* job_normalize(napi_env env, napi_value* a) {   // (channels, sampleRate, targetLUFS, ceilingDB)
+Job* job_normalize(napi_env env, napi_value* a) {   // (channels, sampleRate, targetLUFS, ceilingDB[, onProgress])
   auto j = std::make_unique<Job>();
   if (!get_audio(env, a[0], &j->in)) return nullptr;
   napi_get_value_double(env, a[1], &j->d[0]); napi_get_value_double(env, a[2], &j->d[1]); napi_get_value_double(env, a[3], &j->d[2]);
   j->work = [](Job& j) {
     j.alloc_out(); auto p = j.in.ptrs(); auto o = j.out_ptrs(); wam_normalize_result r;
-    int rc = wam_normalize(p.data(), (int)p.size(), j.in.n, j.d[0], j.d[1], j.d[2], o.data(), &r);
+    int rc = wam_normalize(p.data(), (int)p.size(), j.in.n, j.d[0], j.d[1], j.d[2], o.data(), &r, j.tsfn ? progress_trampoline : nullptr, &j);
     j.d[3] = r.current_lufs; j.d[4] = r.final_lufs; j.d[5] = r.peak_db; j.d[6] = r.gain_applied_db; j.i32[0] = r.limiter_applied; j.i32[1] = r.measured; return rc;
   };
   j->finish = [](napi_env env, Job& j) {          // same keys as dsp-worker.js:468,507-526
@@ -226,7 +227,7 @@ Job* job_normalize(napi_env env, napi_value* a) {   // (channels, sampleRate, ta
   };
   return j.release();
 }
-// generic stage: (name, channels, sampleRate, params[]) -> channels
+// generic stage: (name, channels, sampleRate, params[][, onProgress]) -> channels   (only 'limiter' reports progress: APPLY_LIMITER)
 Job* job_stage(napi_env env, napi_value* a) {
   auto j = std::make_unique<Job>();
   char name[32] = ""; size_t nl = 0; napi_get_value_string_utf8(env, a[0], name, sizeof(name), &nl);
@@ -240,7 +241,7 @@ Job* job_stage(napi_env env, napi_value* a) {
     j.alloc_out(); auto p = j.in.ptrs(); auto o = j.out_ptrs(); const int nch = (int)p.size(); const double sr = j.d[0]; const double* q = &j.d[1];
     if (nm == "finalFilters") return wam_final_filters(p.data(), nch, j.in.n, sr, q[0] != 0, q[1] != 0, o.data());
     if (nm == "softClip") return wam_soft_clip(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], o.data());
-    if (nm == "limiter") return wam_limiter(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], q[4] != 0, o.data());
+    if (nm == "limiter") return wam_limiter(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], q[4] != 0, o.data(), j.tsfn ? progress_trampoline : nullptr, &j);
     if (nm == "limiterLib") return wam_limiter_lib(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], q[4] != 0, o.data());
     if (nm == "glue") return wam_glue_compressor(p.data(), nch, j.in.n, sr, q[0], q[1], q[2], q[3], o.data());
     if (nm == "stereo") return wam_stereo(p.data(), j.in.n, sr, q[0], q[1] != 0, q[2], o.data());
@@ -266,13 +267,14 @@ napi_value sync_entry(napi_env env, napi_callback_info info) {
   j->run();
   return throw_or_result(env, *j);
 }
-template <Job* (*Build)(napi_env, napi_value*)>
+// PROGRESS: index of the optional onProgress(progress, status) argument, -1 = the call reports none
+template <Job* (*Build)(napi_env, napi_value*), int PROGRESS = -1>
 napi_value async_entry(napi_env env, napi_callback_info info) {
   napi_value a[6]; size_t argc = 6; napi_value undef; napi_get_undefined(env, &undef);
   for (auto& v : a) v = undef;
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
   Job* j = Build(env, a); if (!j) return nullptr;
-  return start_async(env, j, nullptr);
+  return start_async(env, j, PROGRESS >= 0 ? a[PROGRESS] : nullptr);
 }
 Job* build_render_sync(napi_env e, napi_value* a) { return job_render(e, a, false); }
 Job* build_render_async(napi_env e, napi_value* a) { return job_render(e, a, true); }
@@ -330,12 +332,12 @@ napi_value stft_db(napi_env env, napi_callback_info info) {          // (channel
 }
 napi_value dc_offset(napi_env env, napi_callback_info info) {        // (channels[, remove]) -> {dc: number[], channels?}
   napi_value a[2]; size_t argc = 2; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
-  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  Audio in; if (!get_audio(env, a[0], &in, 64)) return nullptr;
   bool remove = false; if (argc >= 2) { napi_value b; if (napi_coerce_to_bool(env, a[1], &b) == napi_ok) napi_get_value_bool(env, b, &remove); }
   std::vector<std::vector<float>> out; std::vector<float*> op;
   if (remove) { out.assign(in.ch.size(), std::vector<float>((size_t)in.n)); for (auto& c : out) op.push_back(c.data()); }
-  double dc[2] = {0, 0}; auto p = in.ptrs();
-  if (wam_dc_offset(p.data(), (int)p.size(), in.n, dc, remove ? 1 : 0, remove ? op.data() : nullptr)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
+  std::vector<double> dc(in.ch.size(), 0.0); auto p = in.ptrs();
+  if (wam_dc_offset(p.data(), (int)p.size(), in.n, dc.data(), remove ? 1 : 0, remove ? op.data() : nullptr)) { napi_throw_error(env, nullptr, wam_last_error()); return nullptr; }
   napi_value o, arr; napi_create_object(env, &o); napi_create_array_with_length(env, in.ch.size(), &arr);
   for (size_t c = 0; c < in.ch.size(); c++) { napi_value v; napi_create_double(env, dc[c], &v); napi_set_element(env, arr, (uint32_t)c, v); }
   napi_set_named_property(env, o, "dc", arr);
@@ -386,7 +388,7 @@ napi_value extract_peaks(napi_env env, napi_callback_info info) {    // (channel
 }
 napi_value lufs_series(napi_env env, napi_callback_info info) {      // (channels, sampleRate, positions: Float64Array, momentary) -> Float64Array
   napi_value a[4]; size_t argc = 4; NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
-  Audio in; if (!get_audio(env, a[0], &in)) return nullptr;
+  Audio in; if (!get_audio(env, a[0], &in, 64)) return nullptr;
   double sr = 0; napi_get_value_double(env, a[1], &sr);
   napi_typedarray_type tt; size_t count = 0; void* pos = nullptr; napi_value pab; size_t off;
   if (argc < 3 || napi_get_typedarray_info(env, a[2], &tt, &count, &pos, &pab, &off) != napi_ok || tt != napi_float64_array) {
@@ -417,9 +419,9 @@ napi_value Init(napi_env env, napi_value exports) {
     {"renderChainSync", nullptr, sync_entry<build_render_sync>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"renderChain", nullptr, render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"normalizeSync", nullptr, sync_entry<job_normalize>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
-    {"normalize", nullptr, async_entry<job_normalize>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"normalize", nullptr, async_entry<job_normalize, 4>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stageSync", nullptr, sync_entry<job_stage>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
-    {"stage", nullptr, async_entry<job_stage>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"stage", nullptr, async_entry<job_stage, 4>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"encodePcm24", nullptr, encode_pcm24, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"encodePcm16", nullptr, encode_pcm16, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stftDb", nullptr, stft_db, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

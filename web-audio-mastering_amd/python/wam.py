@@ -236,7 +236,7 @@ def render_full_chain(chans, sr, settings, mode="export", on_progress=None):
     pout, outs = _outs(keep)
     s = settings if isinstance(settings, Settings) else Settings.from_js(settings)
     res = Result()
-    cb = PROGRESS_CB(lambda p, st, u: int(bool(on_progress(p, st.decode())))) if on_progress else C.cast(None, PROGRESS_CB)
+    cb = _progress_cb(on_progress)
     _check(lib().wam_render_chain(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.byref(s),
                                   C.c_int(1 if mode == "export" else 0), pout, C.byref(res), cb, None))
     return outs, res
@@ -273,10 +273,23 @@ def apply_parametric_eq(chans, sr, gains, cut_mud=False):
     return _stage(lib().wam_parametric_eq, chans, C.c_double(sr), g, C.c_int(int(cut_mud)))
 
 
-def apply_lookahead_limiter(chans, sr, ceiling_linear, lookahead_ms=3.0, release_ms=100.0, knee_db=3.0, preserve_transients=True, twin="worker"):
-    """twin="worker": applyLookaheadLimiterToChannels (dsp-worker.js:286); twin="lib": applyLookaheadLimiter (web/lib/dsp/limiter.js:155)"""
-    return _stage(lib().wam_limiter_lib if twin == "lib" else lib().wam_limiter, chans, C.c_double(sr), C.c_double(ceiling_linear), C.c_double(lookahead_ms), C.c_double(release_ms),
-                  C.c_double(knee_db), C.c_int(int(preserve_transients)))
+def _progress_cb(on_progress):
+    return PROGRESS_CB(lambda p, st, u: int(bool(on_progress(p, st.decode())))) if on_progress else C.cast(None, PROGRESS_CB)
+
+
+def apply_lookahead_limiter(chans, sr, ceiling_linear, lookahead_ms=3.0, release_ms=100.0, knee_db=3.0, preserve_transients=True, twin="worker",
+                            on_progress=None):
+    """twin="worker": applyLookaheadLimiterToChannels (dsp-worker.js:286; message APPLY_LIMITER with its PROGRESS stream);
+    twin="lib": applyLookaheadLimiter (web/lib/dsp/limiter.js:155)"""
+    if twin == "lib":
+        return _stage(lib().wam_limiter_lib, chans, C.c_double(sr), C.c_double(ceiling_linear), C.c_double(lookahead_ms), C.c_double(release_ms),
+                      C.c_double(knee_db), C.c_int(int(preserve_transients)))
+    pin, keep = _ptrs(chans)
+    pout, outs = _outs(keep)
+    cb = _progress_cb(on_progress)
+    _check(lib().wam_limiter(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(ceiling_linear), C.c_double(lookahead_ms),
+                             C.c_double(release_ms), C.c_double(knee_db), C.c_int(int(preserve_transients)), pout, cb, None))
+    return outs
 
 
 def apply_exciter(chans, sr):
@@ -300,12 +313,14 @@ def apply_gain(chans, gain_db):
     return _stage(lib().wam_apply_gain, chans, C.c_double(gain_db))
 
 
-def normalize(chans, sr, target_lufs=-14.0, ceiling_db=-1.0):
+def normalize(chans, sr, target_lufs=-14.0, ceiling_db=-1.0, on_progress=None):
     """DSPWorkerInterface.normalize - worker-interface.js:197"""
     pin, keep = _ptrs(chans)
     pout, outs = _outs(keep)
     res = NormalizeResult()
-    _check(lib().wam_normalize(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(target_lufs), C.c_double(ceiling_db), pout, C.byref(res)))
+    cb = _progress_cb(on_progress)
+    _check(lib().wam_normalize(pin, C.c_int(len(keep)), C.c_int64(len(keep[0])), C.c_double(sr), C.c_double(target_lufs), C.c_double(ceiling_db), pout, C.byref(res),
+                               cb, None))
     return outs, res
 
 
