@@ -148,6 +148,15 @@ int wam_render_chain(const float* const* ch, int nch, int64_t n, double sample_r
 int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sample_rate,
                      const wam_settings* settings, int mode, float* const* out, wam_result* results);
 
+/* The same batch over several devices of one node (the north-star's "multi-track batches shard track-wise across the GPUs";
+ * it batches what DSPWorkerInterface.renderFullChain(), worker-interface.js:259-277, does one track at a time): entry i of
+ * `devices` renders the contiguous track range [ceil(i * ntracks / ndev), ceil((i + 1) * ntracks / ndev)) on HIP device
+ * devices[i], from its own host thread with its own streams; per-track results are written at their track index.  No
+ * collective, no peer traffic.  A device may be listed more than once.  The calling thread keeps its device. */
+int wam_batch_render_multi(const float* const* in, int ntracks, int nch, int64_t n, double sample_rate,
+                           const wam_settings* settings, int mode, float* const* out, wam_result* results,
+                           const int* devices, int ndev);
+
 /* Device-resident batch: `in_dev` / `out_dev` are device pointers to
  * [ntracks][nch][n] float32, contiguous.  Enqueues on `stream` and returns after
  * the results have been copied back (it synchronises the stream once). */

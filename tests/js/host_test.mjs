@@ -26,7 +26,7 @@ function track(c) {
 async function cpu() {
   for (const name of ['measureLUFS', 'measureShortTermLUFS', 'measureMomentaryLUFS', 'measureLUFSSeries', 'extractPeaks', 'resampleAudioBuffer', 'analyzeOnLoad', 'findTruePeak', 'normalizeToLUFS', 'applyGain', 'applyLookaheadLimiter', 'applyMasteringSoftClip',
     'applyFinalFilters', 'processHybridDynamic', 'applyExciter', 'applyTapeWarmth', 'applyMultibandTransient', 'detectDCOffsetBuffer',
-    'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
+    'removeDCOffset', 'encodeWAV', 'encodeWAVAsync', 'renderBatch', 'WamWorker', 'DSPWorkerInterface', 'getDSPWorker', 'initDSPWorker'])
     ok(typeof wam[name] === 'function', `export ${name}`);
   const w = new wam.DSPWorkerInterface();
   ok(w.isReady === false, 'not ready before init');
@@ -201,6 +201,19 @@ async function gpu() {
       ok(Math.abs(wam.measureLUFS(ab) - c.lufs) <= 0.01 && Math.abs(wam.findTruePeak(ab) - c.tp_db) <= 0.01, `${name} through the JS surface`);
       ok(Math.abs(wam.measureShortTermLUFS(ab, c.short_term[1][0]) - c.short_term[1][1]) <= 0.01, `${name} short-term`);
     } }
+  // multi-device batch: two entries on device 0, three tracks - each track equals its single render bit for bit
+  { const c = golden['chain_core_1s'];
+    const abs = [0, 1, 2].map((k) => track(Object.assign({}, c, { idx: c.idx + k })));
+    const batch = await wam.renderBatch(abs, c.settings, c.mode, { devices: [0, 0] });
+    ok(batch.length === 3, 'renderBatch returns one result per track');
+    for (let k = 0; k < 3; k++) {
+      const one = await w.renderFullChain(abs[k], c.settings, c.mode);
+      ok(maxAbsDiff(batch[k].audioBuffer.getChannelData(0), one.audioBuffer.getChannelData(0)) === 0 &&
+         maxAbsDiff(batch[k].audioBuffer.getChannelData(1), one.audioBuffer.getChannelData(1)) === 0 && batch[k].lufs === one.lufs, `renderBatch track ${k} equals renderFullChain`);
+    }
+    ok(maxAbsDiff(batch[0].audioBuffer.getChannelData(0), f32(c.out[0])) <= 1e-5, 'renderBatch track 0 vs reference golden');
+    let msg = ''; try { await wam.renderBatch(abs, c.settings, c.mode, { devices: [99] }); } catch (e) { msg = e.message; }
+    ok(/out of range/.test(msg), `renderBatch rejects a bad device, got '${msg}'`); }
   // normalize + terminate semantics
   { const c = golden['meter_10s_48k']; const ab = track(c);
     const r = await w.normalize(ab, -14, -1);

@@ -156,6 +156,30 @@ def test_host_batch_equals_single():
         wam.batch_render(tracks[:2], 0.0, s, "export")
 
 
+def test_multi_device_batch_equals_single():
+    """wam_batch_render_multi: contiguous track ranges per device entry, one host thread + streams per entry,
+    results concatenated in track order.  One GPU on the box: devices = [0, 0] are two workers on it; [0, 0, 0] over 23 tracks gives
+    ranges of 8, 8, 7.  Every track equals its single-track render bit for bit, results included, and the oracle to the bar."""
+    sr, n = 48000, 20000
+    s = dict(wam.DEFAULT_SETTINGS, glueCompression=True)
+    tracks = [O.synth(200 + t, 2, n, sr, {"amp": 1.2 + 0.02 * t, "clickAmp": 0.5}) for t in range(23)]
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        outs, res = wam.batch_render(tracks, sr, s, "export", devices=devices)
+        for t in (0, 7, 8, 11, 12, 15, 16, 22):
+            y, r = wam.render_full_chain(tracks[t], sr, s, "export")
+            assert all(np.array_equal(a, b) for a, b in zip(outs[t], y)), (devices, t)
+            assert res[t].lufs == r.lufs and res[t].true_peak_db == r.true_peak_db and res[t].gain_db == r.gain_db
+    yo, ro = O.render_chain(tracks[12], sr, s, "export")
+    assert maxerr(outs[12], yo) <= PCM_TOL
+    outs, res = wam.batch_render(tracks[:2], sr, s, "export", devices=[0, 0, 0, 0])        # more entries than tracks: empty ranges
+    assert all(np.array_equal(a, b) for a, b in zip(outs[1], wam.render_full_chain(tracks[1], sr, s, "export")[0]))
+    with pytest.raises(wam.WamError, match="out of range"):
+        wam.batch_render(tracks[:2], sr, s, "export", devices=[0, 99])
+    with pytest.raises(wam.WamError):
+        wam.batch_render(tracks[:2], sr, s, "export", devices=[])
+    assert wam.measure_lufs(tracks[0], sr) == wam.measure_lufs(tracks[0], sr)              # the calling thread still has its device
+
+
 def test_hot_material_margin():
     """The soft clipper multiplies upstream differences by up to ~550 near its threshold, so a hard-driven master
     is the severest parity case there is.  Every stage ahead of the clipper is faithful to the reference's f32 stores - the

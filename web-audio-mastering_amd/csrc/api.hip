@@ -111,6 +111,13 @@ void prof_end(int ticket, hipStream_t s) {
   if (ticket < (int)g_prof.size()) (void)hipEventRecord(g_prof[ticket].b, s);     // (wam_profile_read clears the log: callers read it between steps)
 }
 
+// Binds the calling thread to `device` without touching the process default (worker threads of the batch entry points).
+int bind_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
+  g_device = device;
+  return WAM_OK;
+}
+
 int ensure_device() {
   if (g_device >= 0) {
     if (hipSetDevice(g_device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g_device); return WAM_ERR_NO_DEVICE; }

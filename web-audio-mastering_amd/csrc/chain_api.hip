@@ -461,27 +461,22 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
   return render_batch_dev(in_dev, out_dev, ntracks, nch, n, sr, settings, mode, results, (hipStream_t)stream, nullptr, nullptr);
 }
 
-// Host-pointer batch.  Tracks go through the device in staging groups of 8; up to eight host threads, each with its own stream
-// and staging buffers, pull groups from a shared counter, so some groups' H2D / D2H copies run while other groups' kernels do
-// (copies from pageable memory are staged by the runtime and block their thread: 1 thread moves ~18 GB/s, 8 threads ~35 GB/s
-// against 221 ms of kernels per 128 tracks).  Results are independent of the split: tracks never interact.
-int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
-                     float* const* out, wam_result* results) {
-  if (!in || !out || ntracks < 1 || nch < 1 || nch > 2 || n < 0) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
-  for (int64_t i = 0; i < (int64_t)ntracks * nch; i++) if ((!in[i] || !out[i]) && n > 0) { set_error("channel pointer %lld is NULL", (long long)i); return WAM_ERR_INVALID; }
-  int rc = ensure_device(); if (rc) return rc;
-  int device = 0; WAM_HIP(hipGetDevice(&device));
+// Host-pointer batch on ONE device.  Tracks go through the device in staging groups of 8; up to `max_workers` host threads, each
+// with its own stream and staging buffers, pull groups from a shared counter, so some groups' H2D / D2H copies run while other
+// groups' kernels do (copies from pageable memory are staged by the runtime and block their thread: 1 thread moves ~18 GB/s,
+// 8 threads ~35 GB/s against 221 ms of kernels per 128 tracks).  Results are independent of the split: tracks never interact.
+static int batch_render_host(int device, const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
+                             float* const* out, wam_result* results, int max_workers) {
   const size_t per = (size_t)nch * (size_t)(n > 0 ? n : 1);
   const int group = 8;                                // tracks per staging group
   const int ngroups = (ntracks + group - 1) / group;
-  const int nworkers = ngroups < 8 ? ngroups : 8;
+  const int nworkers = ngroups < max_workers ? ngroups : max_workers;
   std::atomic<int> next{0};
   std::vector<int> rcs(nworkers, WAM_OK);
   std::vector<std::string> errs(nworkers);
   auto worker = [&](int w) {
     auto fail = [&](int code) { rcs[w] = code; errs[w] = wam_last_error(); next.store(ngroups); };   // error strings are per thread
-    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return fail(WAM_ERR_NO_DEVICE); }
-    if (wam_init(device) != WAM_OK) return fail(WAM_ERR_NO_DEVICE);
+    if (bind_device(device) != WAM_OK) return fail(WAM_ERR_NO_DEVICE);
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(WAM_ERR_HIP); }
     auto body = [&]() -> int {
@@ -513,6 +508,51 @@ int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, do
   worker(0);
   for (auto& t : extra) t.join();
   for (int w = 0; w < nworkers; w++) if (rcs[w]) { set_error("%s", errs[w].c_str()); return rcs[w]; }
+  return WAM_OK;
+}
+
+static int check_batch(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, float* const* out) {
+  if (!in || !out || !settings || ntracks < 1 || nch < 1 || nch > 2 || n < 0 || !(sr > 0)) { set_error("invalid batch arguments"); return WAM_ERR_INVALID; }
+  for (int64_t i = 0; i < (int64_t)ntracks * nch; i++) if ((!in[i] || !out[i]) && n > 0) { set_error("channel pointer %lld is NULL", (long long)i); return WAM_ERR_INVALID; }
+  return WAM_OK;
+}
+
+int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
+                     float* const* out, wam_result* results) {
+  int rc = check_batch(in, ntracks, nch, n, sr, settings, out); if (rc) return rc;
+  rc = ensure_device(); if (rc) return rc;
+  int device = 0; WAM_HIP(hipGetDevice(&device));
+  return batch_render_host(device, in, ntracks, nch, n, sr, settings, mode, out, results, 8);
+}
+
+// Multi-device batch: entry i of `devices` renders the contiguous track range
+// [ceil(i ntracks / ndev), ceil((i + 1) ntracks / ndev)) - track t belongs to entry floor(t ndev / ntracks), the rule of
+// wam_dist.shard_range - on HIP device devices[i], from a host thread of its own with its own streams and staging
+// buffers.  No collective: tracks are independent, the per-track results land in the caller's array at their track index.
+// A device may appear more than once (two workers sharing one GPU).
+int wam_batch_render_multi(const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
+                           float* const* out, wam_result* results, const int* devices, int ndev) {
+  int rc = check_batch(in, ntracks, nch, n, sr, settings, out); if (rc) return rc;
+  if (!devices || ndev < 1 || ndev > 64) { set_error("invalid device list (1..64 entries)"); return WAM_ERR_INVALID; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error("no HIP device available (this backend has no CPU path)"); return WAM_ERR_NO_DEVICE; }
+  for (int i = 0; i < ndev; i++) if (devices[i] < 0 || devices[i] >= count) { set_error("devices[%d] = %d out of range (0..%d)", i, devices[i], count - 1); return WAM_ERR_INVALID; }
+  int before = -1; (void)hipGetDevice(&before);
+  const int per_dev_workers = ndev >= 4 ? 2 : 8 / ndev;                // staging threads per entry: ~8 in all
+  std::vector<int> rcs(ndev, WAM_OK);
+  std::vector<std::string> errs(ndev);
+  auto entry = [&](int i) {
+    const int64_t lo = ((int64_t)i * ntracks + ndev - 1) / ndev, hi = ((int64_t)(i + 1) * ntracks + ndev - 1) / ndev;
+    if (hi <= lo) return;
+    rcs[i] = batch_render_host(devices[i], in + lo * nch, (int)(hi - lo), nch, n, sr, settings, mode, out + lo * nch, results ? results + lo : nullptr, per_dev_workers);
+    if (rcs[i]) errs[i] = wam_last_error();
+  };
+  std::vector<std::thread> threads;
+  for (int i = 1; i < ndev; i++) threads.emplace_back(entry, i);
+  entry(0);
+  for (auto& t : threads) t.join();
+  if (before >= 0) (void)bind_device(before);                           // entry 0 ran on the caller's thread: restore its device
+  for (int i = 0; i < ndev; i++) if (rcs[i]) { set_error("device entry %d (device %d): %s", i, devices[i], errs[i].c_str()); return rcs[i]; }
   return WAM_OK;
 }
 

@@ -13,6 +13,7 @@ namespace wam {
 
 void set_error(const char* fmt, ...);
 int ensure_device();                       // 0 or WAM_ERR_NO_DEVICE; binds the thread to the device chosen by wam_init
+int bind_device(int device);               // binds the calling thread to `device`; the process default (wam_init) stays
 
 #define WAM_HIP(call)                                                                          \
   do {                                                                                         \

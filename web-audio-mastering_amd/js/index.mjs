@@ -180,6 +180,19 @@ export function stftDb(audioBuffer, nfft = 4096, hop = 1024) {                  
   return addon().stftDb(chansOf(audioBuffer), audioBuffer.sampleRate, nfft, hop);
 }
 
+// A batch of tracks of one shape through the full chain (what renderFullChain, worker-interface.js:259-277, does one track at a
+// time): options.devices = HIP device indices; entry i renders the contiguous track range [ceil(i T / D), ceil((i + 1) T / D)) on
+// its device from its own host thread (no collective - tracks are independent); without it the batch runs on the current device.
+// Resolves to one {audioBuffer, lufs, measuredLufs, truePeakDb, inputLufs, gainDb} per track, in track order.
+export async function renderBatch(audioBuffers, settings, mode = 'export', options = {}) {
+  if (!Array.isArray(audioBuffers) || audioBuffers.length === 0) throw new Error('renderBatch: audioBuffers must be a non-empty array');
+  const sr = audioBuffers[0].sampleRate;
+  if (audioBuffers.some((ab) => ab.sampleRate !== sr)) throw new Error('renderBatch: tracks of a batch share one sample rate');
+  const res = await addon().renderBatch(audioBuffers.map(chansOf), sr, settings, mode, options.devices);
+  return res.map((r) => ({ audioBuffer: makeAB(r.channels, sr), lufs: r.lufs, measuredLufs: r.measuredLufs, truePeakDb: r.truePeakDb,
+    inputLufs: r.inputLufs, gainDb: r.gainDb }));
+}
+
 // ---- web/workers/dsp-worker.js as a Worker-shaped object ---------------------------------------------
 // `new WamWorker()` stands where the reference does `new Worker(new URL('./dsp-worker.js', ...))` (worker-interface.js:29-32):
 // same message protocol (dsp-worker.js:1-9) - request {type, id, data}, reply {id, success, result} or

@@ -401,6 +401,76 @@ napi_value lufs_series(napi_env env, napi_callback_info info) {      // (channel
   NAPI_CALL(env, napi_create_typedarray(env, napi_float64_array, count, ab, 0, &ta));
   return ta;
 }
+// renderBatch(tracks: Float32Array[][], sampleRate, settings, mode, devices?: number[]) -> Promise<{channels, lufs, measuredLufs, truePeakDb, inputLufs, gainDb}[]>
+// wam_batch_render_multi (devices given: contiguous track ranges, one host thread + streams per entry) or wam_batch_render (current device).
+struct BatchJob {
+  std::vector<Audio> tracks;
+  std::vector<std::vector<std::vector<float>>> out;
+  std::vector<wam_result> res;
+  std::vector<int> devices;
+  wam_settings settings; int mode = 1; double sr = 0;
+  int rc = 0; std::string err;
+  napi_async_work aw = nullptr; napi_deferred deferred = nullptr;
+};
+void batch_execute(napi_env, void* data) {
+  BatchJob* j = (BatchJob*)data;
+  const int nt = (int)j->tracks.size(), nch = (int)j->tracks[0].ch.size(); const int64_t n = j->tracks[0].n;
+  std::vector<const float*> in; std::vector<float*> out;
+  j->out.assign(nt, std::vector<std::vector<float>>(nch, std::vector<float>((size_t)n)));
+  for (int t = 0; t < nt; t++) for (int c = 0; c < nch; c++) { in.push_back(j->tracks[t].ch[c].data()); out.push_back(j->out[t][c].data()); }
+  j->res.resize(nt);
+  j->rc = j->devices.empty() ? wam_batch_render(in.data(), nt, nch, n, j->sr, &j->settings, j->mode, out.data(), j->res.data())
+                             : wam_batch_render_multi(in.data(), nt, nch, n, j->sr, &j->settings, j->mode, out.data(), j->res.data(), j->devices.data(), (int)j->devices.size());
+  if (j->rc) j->err = wam_last_error();
+}
+void batch_complete(napi_env env, napi_status, void* data) {
+  BatchJob* j = (BatchJob*)data;
+  if (j->rc) { napi_value msg, e; napi_create_string_utf8(env, j->err.c_str(), NAPI_AUTO_LENGTH, &msg); napi_create_error(env, nullptr, msg, &e); napi_reject_deferred(env, j->deferred, e); }
+  else {
+    napi_value arr; napi_create_array_with_length(env, j->out.size(), &arr);
+    for (size_t t = 0; t < j->out.size(); t++) {
+      napi_value o; napi_create_object(env, &o);
+      napi_set_named_property(env, o, "channels", make_channels(env, j->out[t]));
+      const wam_result& r = j->res[t];
+      set_num(env, o, "lufs", r.lufs); set_num(env, o, "measuredLufs", r.measured_lufs); set_num(env, o, "truePeakDb", r.true_peak_db);
+      set_num(env, o, "inputLufs", r.lufs_in); set_num(env, o, "gainDb", r.gain_db);
+      napi_set_element(env, arr, (uint32_t)t, o);
+    }
+    napi_resolve_deferred(env, j->deferred, arr);
+  }
+  napi_delete_async_work(env, j->aw);
+  delete j;
+}
+napi_value render_batch(napi_env env, napi_callback_info info) {
+  napi_value a[5]; size_t argc = 5; napi_value undef; napi_get_undefined(env, &undef); for (auto& v : a) v = undef;
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  bool is_arr = false; uint32_t nt = 0;
+  if (napi_is_array(env, a[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, a[0], &nt) != napi_ok || nt < 1) {
+    napi_throw_type_error(env, nullptr, "tracks must be a non-empty array of channel arrays"); return nullptr;
+  }
+  auto j = std::make_unique<BatchJob>();
+  j->tracks.resize(nt);
+  for (uint32_t t = 0; t < nt; t++) {
+    napi_value tr; napi_get_element(env, a[0], t, &tr);
+    if (!get_audio(env, tr, &j->tracks[t])) return nullptr;
+    if (j->tracks[t].ch.size() != j->tracks[0].ch.size() || j->tracks[t].n != j->tracks[0].n) { napi_throw_range_error(env, nullptr, "tracks of a batch share one shape"); return nullptr; }
+  }
+  napi_get_value_double(env, a[1], &j->sr);
+  j->settings = get_settings(env, a[2]);
+  char mode[16] = "preview"; size_t ml = 0; napi_valuetype t; napi_typeof(env, a[3], &t);
+  if (t == napi_string) napi_get_value_string_utf8(env, a[3], mode, sizeof(mode), &ml);
+  j->mode = std::strcmp(mode, "export") == 0 ? WAM_MODE_EXPORT : WAM_MODE_PREVIEW;
+  bool dev_arr = false; napi_is_array(env, a[4], &dev_arr);
+  if (dev_arr) { uint32_t nd = 0; napi_get_array_length(env, a[4], &nd); for (uint32_t i = 0; i < nd; i++) { napi_value v; napi_get_element(env, a[4], i, &v); int32_t d = 0; napi_get_value_int32(env, v, &d); j->devices.push_back(d); } }
+  napi_value promise, name;
+  NAPI_CALL(env, napi_create_promise(env, &j->deferred, &promise));
+  napi_create_string_utf8(env, "wam-batch", NAPI_AUTO_LENGTH, &name);
+  BatchJob* raw = j.release();
+  NAPI_CALL(env, napi_create_async_work(env, nullptr, name, batch_execute, batch_complete, raw, &raw->aw));
+  NAPI_CALL(env, napi_queue_async_work(env, raw->aw));
+  return promise;
+}
+
 napi_value init_dev(napi_env env, napi_callback_info info) {
   napi_value a[1]; size_t argc = 1; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
   int32_t dev = 0; if (argc >= 1) napi_get_value_int32(env, a[0], &dev);
@@ -418,6 +488,7 @@ napi_value Init(napi_env env, napi_value exports) {
     {"meter", nullptr, async_entry<job_meter>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"renderChainSync", nullptr, sync_entry<build_render_sync>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"renderChain", nullptr, render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    {"renderBatch", nullptr, render_batch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"normalizeSync", nullptr, sync_entry<job_normalize>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"normalize", nullptr, async_entry<job_normalize, 4>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"stageSync", nullptr, sync_entry<job_stage>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

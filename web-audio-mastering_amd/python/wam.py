@@ -362,8 +362,9 @@ def stft_db(chans, sr, nfft=4096, hop=1024, columns=False):
     return (out, cols) if columns else out
 
 
-def batch_render(tracks, sr, settings, mode="export"):
-    """wam_batch_render: host-pointer batch; tracks = list of tracks, each a list of nch float32 arrays of one common length.
+def batch_render(tracks, sr, settings, mode="export", devices=None):
+    """wam_batch_render / wam_batch_render_multi: host-pointer batch; tracks = list of tracks, each a list of nch float32 arrays of
+    one common length; devices = list of HIP device indices (contiguous track ranges, one per entry) or None for the current device.
     Returns (outputs in the same shape, results)."""
     nch, n = len(tracks[0]), len(tracks[0][0])
     keep = [np.ascontiguousarray(c, dtype=np.float32) for t in tracks for c in t]
@@ -372,8 +373,13 @@ def batch_render(tracks, sr, settings, mode="export"):
     pout = (FP * len(outs))(*[a.ctypes.data_as(FP) for a in outs])
     s = settings if isinstance(settings, Settings) else Settings.from_js(settings)
     res = (Result * len(tracks))()
-    _check(lib().wam_batch_render(pin, C.c_int(len(tracks)), C.c_int(nch), C.c_int64(n), C.c_double(sr), C.byref(s),
-                                  C.c_int(1 if mode == "export" else 0), pout, res))
+    if devices is None:
+        _check(lib().wam_batch_render(pin, C.c_int(len(tracks)), C.c_int(nch), C.c_int64(n), C.c_double(sr), C.byref(s),
+                                      C.c_int(1 if mode == "export" else 0), pout, res))
+    else:
+        dv = (C.c_int * len(devices))(*devices)
+        _check(lib().wam_batch_render_multi(pin, C.c_int(len(tracks)), C.c_int(nch), C.c_int64(n), C.c_double(sr), C.byref(s),
+                                            C.c_int(1 if mode == "export" else 0), pout, res, dv, C.c_int(len(devices))))
     return [outs[i * nch:(i + 1) * nch] for i in range(len(tracks))], res
 
 
