@@ -166,6 +166,18 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
 int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
                         double fallback, double* lufs, double* dbtp, void* stream);
 
+/* wam_batch_meter_dev for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code that runs under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels and numbers as wam_batch_meter_dev,
+ * but: (1) what that entry point takes from the library's workspace pool (plan, per-hop sums, peaks, block energies, gate
+ * results) lives in a fixed 64 MiB device array that every GPU holds from the moment it loads the library until the process
+ * ends; (2) the results go to the CALLER's device arrays lufs_dev / dbtp_dev [ntracks] (either may be NULL), so there is
+ * no device-to-host copy and no synchronisation: the call only enqueues on `stream`; (3) it calls no hipMalloc / hipFree or
+ * other allocating routine - call wam_init(device) once beforehand, which looks the array's address up on that device.
+ * A batch whose scratch does not fit (1,024 three-minute stereo tracks need 44.5 MB) is refused with WAM_ERR_TOO_LARGE.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two host threads, two streams) race. */
+int wam_batch_meter_dev_noalloc(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
+                                double fallback, double* lufs_dev, double* dbtp_dev, void* stream);
+
 /* What web/app.js:823-872 does on every file load, as one call with one upload: detectDCOffsetBuffer
  * (dc-offset.js:38-60); removeDCOffset on every channel when any channel's |mean| > 0.001 (app.js:828-834); measureLUFS and
  * findTruePeak of the result (:865-866); normalizeToLUFS(buffer, target_lufs, ceiling_db) with the library limiter when the

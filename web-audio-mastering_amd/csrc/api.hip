@@ -112,9 +112,11 @@ void prof_end(int ticket, hipStream_t s) {
 }
 
 // Binds the calling thread to `device` without touching the process default (worker threads of the batch entry points).
+int noalloc_bind_scratch(int device);      // noalloc.hip: per-device address of the fixed scratch array, looked up with the device current
 int bind_device(int device) {
   if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
   g_device = device;
+  (void)noalloc_bind_scratch(device);      // (wam_batch_meter_dev_noalloc reports a failed look-up itself)
   return WAM_OK;
 }
 
@@ -266,6 +268,7 @@ int wam_init(int device) {
   if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return WAM_ERR_NO_DEVICE; }
   g_device = device;
   g_default_device.store(device);          // threads that never called wam_init (libuv workers) follow the LAST explicit choice
+  (void)noalloc_bind_scratch(device);      // set-up for wam_batch_meter_dev_noalloc: once per device, with that device current (it reports a failed look-up itself)
   return WAM_OK;
 }
 

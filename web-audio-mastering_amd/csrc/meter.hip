@@ -309,6 +309,41 @@ int enqueue_norm_gain(const MeterScratch& s, int ntracks, double target, double*
   return WAM_OK;
 }
 
+// The plan travels as a kernel argument (no host-to-device copy, nothing staged by the runtime): for callers that may not allocate.
+__global__ void k_store_plan(MeterPlan pl, MeterPlan* __restrict__ dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = pl; }
+
+// finish_lufs / finish_peak_db on the device, into the caller's device arrays (either may be NULL)
+__global__ void k_finish_meter(const GateOut* __restrict__ gate, const MeterPlan* __restrict__ plan, int ntracks,
+                               double* __restrict__ lufs, double* __restrict__ dbtp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntracks) return;
+  const MeterPlan& pl = *plan;
+  const GateOut g = gate[t];
+  if (lufs) {
+    double v;
+    if (pl.too_short) v = pl.fallback;                                  // lufs.js:23-26
+    else if (g.nblocks == 0 || g.c1 == 0 || g.c2 == 0) v = -INFINITY;   // :68,72,77
+    else v = -0.691 + 10 * log10(g.mean2);                              // :81
+    lufs[t] = v;
+  }
+  if (dbtp) dbtp[t] = g.peak > 0 ? 20 * log10(g.peak) : -INFINITY;      // true-peak.js:70
+}
+
+int enqueue_meter_to_device(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, double* lufs_dev,
+                            double* dbtp_dev, hipStream_t stream) {
+  WAM_LAUNCH("k_store_plan", k_store_plan, dim3(1), dim3(64), stream, pl, s.plan);
+  WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));
+  if (n > 0) {
+    const int64_t ntiles = (n + kTile - 1) / kTile, warm = meter_warm(pl.hop, (double)pl.hop * 10.0);
+    const int64_t seg = pick_segment_tiles((int64_t)ntracks * pl.nch, ntiles, warm, tuning().meter_seg_tiles);
+    WAM_LAUNCH("k_meter", k_meter, dim3(ntracks * pl.nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), stream, in_dev, n, (const MeterPlan*)s.plan, s.hopsums,
+               s.hop_stride, s.peaks, seg, warm);
+  }
+  int rc = enqueue_gate(pl, ntracks, s, stream); if (rc) return rc;
+  WAM_LAUNCH("k_finish_meter", k_finish_meter, dim3((ntracks + 63) / 64), dim3(64), stream, (const GateOut*)s.gate, (const MeterPlan*)s.plan, ntracks, lufs_dev, dbtp_dev);
+  return WAM_OK;
+}
+
 int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, hipStream_t stream) {
   WAM_HIP(hipMemcpyAsync(s.plan, &pl, sizeof(MeterPlan), hipMemcpyHostToDevice, stream));
   WAM_HIP(hipMemsetAsync(s.hopsums, 0, s.hopsums_bytes, stream));

@@ -27,6 +27,10 @@ size_t meter_scratch_bytes(const MeterPlan& pl, int ntracks, bool want_mask);
 void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void* scratch, MeterScratch* s);
 // zero hop sums, run k_meter over [ntracks][nch][n] and then k_gate
 int enqueue_meter(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, hipStream_t stream);
+// the same with the plan handed over as a kernel argument and LUFS / dBTP finished on the device into lufs_dev / dbtp_dev [ntracks]:
+// no host <-> device copy, no synchronisation (csrc/noalloc.hip)
+int enqueue_meter_to_device(const float* in_dev, int ntracks, const MeterPlan& pl, int64_t n, const MeterScratch& s, double* lufs_dev,
+                            double* dbtp_dev, hipStream_t stream);
 // out = f32(in * gains[track]) (out may be NULL, gains may be NULL) + metering + gate
 int enqueue_gain_meter(const float* in, float* out, int ntracks, int nch, int64_t n, const double* gains, const MeterPlan& pl,
                        const MeterScratch& s, hipStream_t stream);
