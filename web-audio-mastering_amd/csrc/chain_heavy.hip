@@ -67,13 +67,16 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, &Ptab[0][0], Sst[1], slots.next(), u0, u1);
     double ga, gb;
     biquad_extra2(d, f1, f1a, f1b, P.exc_hp, ga, gb);
-    // filtered[i-1 .. i+2] around each sample; out-of-range reads are 0 (exciter.js:162-184)
+    // filtered[i-1 .. i+2] around each sample; out-of-range reads AND NaN are 0 (`filtered[k] || 0`, exciter.js:162-184: after a
+    // NaN input sample the filter state stays NaN and the reference's wet path falls back to tanh(bias))
     double f[C + 3];
     f[0] = (base - 1 >= 0) ? (double)f32r(u0) : 0.0;
 #pragma unroll
     for (int k = 0; k < C; k++) f[k + 1] = (base + k < n) ? (double)f32r(d[k]) : 0.0;
     f[C + 1] = (base + C < n) ? (double)f32r(ga) : 0.0;
     f[C + 2] = (base + C + 1 < n) ? (double)f32r(gb) : 0.0;
+#pragma unroll
+    for (int k = 0; k < C + 3; k++) f[k] = (f[k] == f[k]) ? f[k] : 0.0;
     float o[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
