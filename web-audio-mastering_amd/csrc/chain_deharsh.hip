@@ -658,7 +658,7 @@ constexpr int kCross = 448;                      // crossing list capacity per f
 // DPP moves for the wavefront scans (no LDS round trip, unlike ds_bpermute): lanes without a source read 0, the identity of
 // the scans below.  row_shr:n = 0x110 + n; row_bcast:15 = 0x142 (lane 15 of every row to the next row, row mask 0xA);
 // row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xC); wave_shr:1 = 0x138.
-template <int CTRL, int RM> __device__ __forceinline__ int dppm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, false); }
+template <int CTRL, int RM> __device__ __forceinline__ int dppm(int v) { return dpp_i<CTRL, RM>(0, v); }
 template <int CTRL, int RM> __device__ __forceinline__ float dppm(float v) { return __int_as_float(dppm<CTRL, RM>(__float_as_int(v))); }
 template <int CTRL, int RM> __device__ __forceinline__ double dppm(double v) {
   return __hiloint2double(dppm<CTRL, RM>(__double2hiint(v)), dppm<CTRL, RM>(__double2loint(v)));

@@ -44,8 +44,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
     biquad_lane_power_table(fp->side_hp, lane, &Pl[kFSide][0][0]);
   }
   for (int i = threadIdx.x; i < (NCH * 9 + 1) * 2; i += kThreads) Sl[i >> 1][i & 1] = 0;
-  const double Plpf = onepole_lane_power(fp->lpf18, lane);
-  double Slpf[NCH] = {}, Senv = 0;
+  __shared__ double PlpfT[64];                    // lane powers of the one-pole low-pass (read where used: two VGPRs less across the tile)
+  if (wave_id() == 1) PlpfT[lane] = onepole_lane_power(fp->lpf18, lane);
+  // tile carries of the one-pole low-pass (per channel) and of the glue follower: uniform over the workgroup, so they live in LDS
+  // (thread 0 stores after the scan, everybody reads at the next tile) and not in six VGPRs per thread
+  __shared__ double Scar[NCH + 1];
+  if (threadIdx.x <= NCH) Scar[threadIdx.x] = 0;
   MeterStateL ms[NCH];
   if (do_meter) for (int c = 0; c < NCH; c++) meter_init_l(ms[c], *mp, sg.Tw * kTile, sg, &Pl[kFShelf][0][0], &Pl[kFKhp][0][0], Sl[c * 9 + 7], Sl[c * 9 + 8]);
   __syncthreads();
@@ -88,12 +92,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
           if (threadIdx.x == 0) { bc[0] = f32r(da[0]); bc[1] = f32r(db[0]); }
           __syncthreads();
           const float f0 = bc[0], f1 = bc[1];
-          Slpf[0] = (f0 == f0) ? (double)f0 : 0.0; Slpf[1] = (f1 == f1) ? (double)f1 : 0.0;
+          if (threadIdx.x == 0) { Scar[0] = (f0 == f0) ? (double)f0 : 0.0; Scar[1] = (f1 == f1) ? (double)f1 : 0.0; }
+          __syncthreads();
         }
         double ua[C], ub[C];
 #pragma unroll
         for (int k = 0; k < C; k++) { ua[k] = P.lpf_alpha * da[k]; ub[k] = P.lpf_alpha * db[k]; }
-        onepole_pair(ua, ub, P.lpf18, Plpf, Slpf[0], Slpf[1], slots.next());
+        double Sa = Scar[0], Sb = Scar[1];                          // (read before the scan's barrier, stored after it)
+        onepole_pair(ua, ub, P.lpf18, PlpfT[lane], Sa, Sb, slots.next());
+        if (threadIdx.x == 0) { Scar[0] = Sa; Scar[1] = Sb; }
 #pragma unroll
         for (int k = 0; k < C; k++) { da[k] = (double)f32r(ua[k]); db[k] = (double)f32r(ub[k]); }
         have_nb = false;
@@ -145,13 +152,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
           if (threadIdx.x == 0) bc[c] = f32r(d[0]);
           __syncthreads();
           const float f0 = bc[c];
-          Slpf[c] = (f0 == f0) ? (double)f0 : 0.0;
+          if (threadIdx.x == 0) Scar[c] = (f0 == f0) ? (double)f0 : 0.0;
+          __syncthreads();
         }
         double u[C];
 #pragma unroll
         for (int k = 0; k < C; k++) u[k] = P.lpf_alpha * d[k];
         double s;
-        onepole_chunk(u, P.lpf18, Plpf, Slpf[c], slots.next(), s);
+        double Sc = Scar[c];
+        onepole_chunk(u, P.lpf18, PlpfT[lane], Sc, slots.next(), s);
+        if (threadIdx.x == 0) Scar[c] = Sc;
 #pragma unroll
         for (int k = 0; k < C; k++) d[k] = (double)f32r(u[k]);
         have_nb = false;
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         if (NCH >= 2) sc = f32r(((double)w[0][k] + (double)w[NCH - 1][k]) * 0.5); else sc = w[0][k];
         a[k] = (base + k < n) ? fabsf(sc) : 0.0f;
       }
+      double Senv = Scar[NCH];
       double e = follower_solve(a, P.glue_A, P.glue_R, Senv, slots.next());
+      if (threadIdx.x == 0) Scar[NCH] = Senv;
 #pragma unroll
       for (int k = 0; k < C; k++) {
         e = follower_step(e, (double)a[k], P.glue_A, P.glue_R);

@@ -137,7 +137,18 @@ __global__ void k_warm_env(const unsigned* __restrict__ winpeak, int ntracks, in
 }
 
 // LR4 three-band split of a chunk (multiband-saturation.js:125-148 / multiband-transient.js:94-132).
-struct SplitState { double P[4][64][4]; double S[8][2]; };      // lives in LDS
+struct SplitState {                                             // lives in LDS
+  double P[4][64][4]; double S[8][2];
+  float4 stash[C / 4][kThreads];                                // the band that waits for its turn: 16 VGPRs less across a consume() (conflict-free: lane-major)
+};
+__device__ __forceinline__ void stash_put(SplitState& st, const float v[C]) {
+#pragma unroll
+  for (int j = 0; j < C / 4; j++) st.stash[j][threadIdx.x] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+__device__ __forceinline__ void stash_get(const SplitState& st, float v[C]) {     // same thread, same slots: no barrier needed
+#pragma unroll
+  for (int j = 0; j < C / 4; j++) { const float4 t = st.stash[j][threadIdx.x]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+}
 __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, const Biquad& hp1, const Biquad& lp2, const Biquad& hp2) {
   if (wave_id() == 0) {
     biquad_lane_power_table(lp1, lane_id(), &st.P[0][0][0]); biquad_lane_power_table(hp1, lane_id(), &st.P[1][0][0]);
@@ -163,23 +174,34 @@ __device__ __forceinline__ void split_chunk(const float v[C], float xm1, float x
   for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
   biquad_pair_lds(da, (double)f32r(a0), (double)f32r(a1), lp1, &st.P[0][0][0], st.S[1],
                   db, (double)f32r(b0), (double)f32r(b1), hp1, &st.P[1][0][0], st.S[3], slots.next(), c0, c1, e0, e1);
-  float mh[C];
+  {
+    float mh[C];
 #pragma unroll
-  for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); mh[k] = f32r(db[k]); }
+    for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); mh[k] = f32r(db[k]); }
+    stash_put(st, mh);                                          // mid + high waits in LDS while the low band is consumed
+  }
   const double mh1 = (double)f32r(e0), mh2 = (double)f32r(e1);
   consume(0, band);
+  {
+    float mh[C];
+    stash_get(st, mh);
 #pragma unroll
-  for (int k = 0; k < C; k++) { da[k] = mh[k]; db[k] = mh[k]; }
+    for (int k = 0; k < C; k++) { da[k] = mh[k]; db[k] = mh[k]; }
+  }
   biquad_pair_lds(da, mh1, mh2, lp2, &st.P[2][0][0], st.S[4], db, mh1, mh2, hp2, &st.P[3][0][0], st.S[6], slots.next(), a0, a1, b0, b1);
 #pragma unroll
   for (int k = 0; k < C; k++) { da[k] = (double)f32r(da[k]); db[k] = (double)f32r(db[k]); }
   biquad_pair_lds(da, (double)f32r(a0), (double)f32r(a1), lp2, &st.P[2][0][0], st.S[5],
                   db, (double)f32r(b0), (double)f32r(b1), hp2, &st.P[3][0][0], st.S[7], slots.next(), c0, c1, e0, e1);
-  float high[C];
+  {
+    float high[C];
 #pragma unroll
-  for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); high[k] = f32r(db[k]); }
+    for (int k = 0; k < C; k++) { band[k] = f32r(da[k]); high[k] = f32r(db[k]); }
+    stash_put(st, high);                                        // and the high band while the mid band is
+  }
   consume(1, band);
-  consume(2, high);
+  stash_get(st, band);
+  consume(2, band);
 }
 
 // WARM / PUNCH are compile-time so that each instantiation carries only its own filter state: the two stages run as
@@ -201,7 +223,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
   SplitState& sw = sw_s; SplitState& sp = sw_s;
   if (do_warm) split_init(sw, hp->w_lp1, hp->w_hp1, hp->w_lp2, hp->w_hp2);
   if (do_punch) split_init(sp, hp->p_lp1, hp->p_hp1, hp->p_lp2, hp->p_hp2);
-  double Sf[3] = {0, 0, 0}, Ss[3] = {0, 0, 0}, Sg[3] = {1, 1, 1};
+  // tile carries of the transient shaper (fast / slow follower and gain smoother per band): the same value in every thread, so they
+  // live in LDS like the filters' carries (thread 0 stores, everybody reads at the next tile) instead of 18 VGPRs per thread
+  __shared__ double Scar[9];
+  if (threadIdx.x < 9) Scar[threadIdx.x] = threadIdx.x < 6 ? 0.0 : 1.0;
   const double Psm = onepole_lane_power(hp->p_smooth, lane_id());
   // bypass-envelope window of this thread's chunk start, advanced tile by tile without divisions
   // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early (LR4 filters: 2 tiles; the slow transient
@@ -269,11 +294,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
         // processTransients, multiband-transient.js:194-263
         const double fA = P.pf_A[b], fR = P.pf_R[b], sA = P.ps_A[b], sR = P.ps_R[b], tg = P.p_tg[b] - 1, sg = P.p_sg[b] - 1;
         const double osm = 1 - P.p_smooth.c;
-        float a[C];                           // rectified input (f32 values, widened where used)
-#pragma unroll
-        for (int k = 0; k < C; k++) a[k] = (base + k < n) ? fabsf(band[k]) : 0.0f;
+        // rectified input: |band| read through a view (an abs source modifier, no second array of 16 registers).  Samples past the
+        // end of the track come after every sample that is stored, so what the followers do with them is immaterial.
+        struct AbsView { const float* p; __device__ __forceinline__ float operator[](int k) const { return fabsf(p[k]); } };
+        const AbsView a{ band };
         double fe, se;
-        follower_solve2(a, fA, fR, Sf[b], sA, sR, Ss[b], slots.next(), fe, se);
+        double Sfb = Scar[b], Ssb = Scar[3 + b];                  // (read before the solve's first barrier, stored after its last)
+        follower_solve2(a, fA, fR, Sfb, sA, sR, Ssb, slots.next(), fe, se);
+        if (threadIdx.x == 0) { Scar[b] = Sfb; Scar[3 + b] = Ssb; }
         double u[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
@@ -286,7 +314,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
           u[k] = osm * target;
         }
         double s;
-        onepole_chunk(u, P.p_smooth, Psm, Sg[b], slots.next(), s);
+        double Sgb = Scar[6 + b];
+        onepole_chunk(u, P.p_smooth, Psm, Sgb, slots.next(), s);
+        if (threadIdx.x == 0) Scar[6 + b] = Sgb;
 #pragma unroll
         for (int k = 0; k < C; k++) {
           const double r = (double)f32r((double)band[k] * u[k]);

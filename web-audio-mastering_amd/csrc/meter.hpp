@@ -82,13 +82,17 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
     // A block that is `rem` samples longer than four hops ends with the first `rem` samples of a fifth hop (lufs.js:57-65 sums
     // sample ranges): those squares are kept one by one, 4 slots per hop, each written by the one workgroup that owns the sample
     // (its own tiles, not its warm-up), so the gate kernel adds them in a fixed order.
+    // (a chunk holds at most one hop start, hop >= C: the head samples are k = k0 .. k0 + rem - 1 with k0 = 0 when the chunk starts
+    // inside a head, else the distance to the next hop)
     double* heads = hopsums + pl.heads_off;
+    const int off = (int)m.hop_off, hop = (int)pl.hop;
+    const int64_t lo = m.own_from > 0 ? m.own_from : 0, hi = m.own_to < n ? m.own_to : n;
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      int64_t pos = m.hop_off + k, h = m.hop_idx;
-      if (pos >= pl.hop) { pos -= pl.hop; h++; }
+      int pos = off + k; int64_t h = m.hop_idx;
+      if (pos >= hop) { pos -= hop; h++; }
       const int64_t i = base + k;
-      if (pos < pl.rem && i < n && i >= m.own_from && i < m.own_to) { const double z = (double)f32r(v[k]); heads[4 * h + pos] = z * z; }
+      if (pos < pl.rem && i >= lo && i < hi) { const double z = (double)f32r(v[k]); heads[4 * h + pos] = z * z; }
     }
   }
   int64_t h_first = tile_base / pl.hop;

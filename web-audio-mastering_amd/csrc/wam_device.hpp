@@ -175,12 +175,18 @@ __device__ __forceinline__ double wave_max(double v) {
 // no lane arithmetic; a lane without a source keeps `old`, which the callers set to the identity of their scan.
 // row_shr:n = 0x110 + n (within rows of 16 lanes); row_bcast:15 = 0x142 with row mask 0xA (lane 15 of rows 0 / 2 to rows
 // 1 / 3); row_bcast:31 = 0x143 with row mask 0xC (lane 31 to rows 2 and 3); wave_shr:1 = 0x138 (lane l - 1).
+// One 32-bit DPP move.  update_dpp needs its destination pre-loaded with `old` (a v_mov of the constant before every DPP move);
+// when `old` is the constant 0 and no row is masked, bound_ctrl:1 supplies the zero for lanes without a source and the
+// pre-load disappears - half of the moves of a scan step on doubles (the low words of 0.0 AND of 1.0 are zero).
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i(int old, int v) {
+  if (RM == 0xF && __builtin_constant_p(old) && old == 0) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xF, false);
+}
 template <int CTRL, int RM> __device__ __forceinline__ float dpp_f(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, RM, 0xF, false));
+  return __int_as_float(dpp_i<CTRL, RM>(__float_as_int(old), __float_as_int(v)));
 }
 template <int CTRL, int RM> __device__ __forceinline__ double dpp_d(double old, double v) {
-  return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, RM, 0xF, false),
-                          __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, RM, 0xF, false));
+  return __hiloint2double(dpp_i<CTRL, RM>(__double2hiint(old), __double2hiint(v)), dpp_i<CTRL, RM>(__double2loint(old), __double2loint(v)));
 }
 // Inclusive scan of affine maps x -> al x + be over the wavefront (lane l: the composition of lanes 0..l, lower lanes
 // applied first): Hillis-Steele inside the rows, then the row aggregates by two broadcasts.
@@ -496,8 +502,9 @@ __device__ __forceinline__ double follower_solve(const T a[C], double A, double 
 // Two followers over the same input (the fast and slow envelopes of the transient shaper), solved in one iteration
 // loop: their runs and scans interleave (instruction-level parallelism for the dependent chains) and they share the
 // barriers; the loop ends when both start values reproduce themselves.  lds: 16 doubles.
+// a: the rectified input of the chunk, anything indexable that yields f32 values (an array, or a view that rectifies on the fly)
 template <class T>
-__device__ __forceinline__ void follower_solve2(const T a[C], double A1, double R1, double& S1, double A2, double R2, double& S2,
+__device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1, double& S1, double A2, double R2, double& S2,
                                                 double* lds, double& start1, double& start2) {
   const int lane = lane_id(), wave = wave_id();
   const double S1_in = S1, S2_in = S2;
