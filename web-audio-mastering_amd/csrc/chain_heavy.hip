@@ -78,14 +78,23 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < C + 3; k++) f[k] = (f[k] == f[k]) ? f[k] : 0.0;
     float o[C];
+    // |tanh argument| <= 1 for the whole wavefront's chunks (the Catmull-Rom midpoint overshoots its neighbours by at most 1.25):
+    // the Pade form; else the general one.  High-passed programme material is far below the bound.
+    double fmx = 0;
 #pragma unroll
-    for (int k = 0; k < C; k++) {
-      const double wetA = tanh_fast(f[k + 1] * drive + bias);
-      const double sB = catmull_half(f[k], f[k + 1], f[k + 2], f[k + 3]);
-      const double wetB = tanh_fast(sB * drive + bias);
-      const double wet = (wetA + wetB) * 0.5;
-      o[k] = f32r((double)v[k] + wet * mix);
-    }
+    for (int k = 0; k < C + 3; k++) fmx = fmax(fmx, fabs(f[k]));
+    auto shape = [&](auto tanh_fn) {
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const double wetA = tanh_fn(f[k + 1] * drive + bias);
+        const double sB = catmull_half(f[k], f[k + 1], f[k + 2], f[k + 3]);
+        const double wetB = tanh_fn(sB * drive + bias);
+        const double wet = (wetA + wetB) * 0.5;
+        o[k] = f32r((double)v[k] + wet * mix);
+      }
+    };
+    if (__all(fmx * (1.25 * drive) + bias <= 1.0)) shape([](double z) { return tanh_small(z); });
+    else shape([](double z) { return tanh_fast(z); });
     if (t >= T0) store_chunk(y, n, base, o);
   }
 }
@@ -227,6 +236,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
   // live in LDS like the filters' carries (thread 0 stores, everybody reads at the next tile) instead of 18 VGPRs per thread
   __shared__ double Scar[9];
   if (threadIdx.x < 9) Scar[threadIdx.x] = threadIdx.x < 6 ? 0.0 : 1.0;
+  __shared__ double alT[6][C + 2];              // follower_al_table per band: fast [b], slow [3 + b]
+  if (do_punch) for (int b = 0; b < 3; b++) { follower_al_table(hp->pf_A[b], hp->pf_R[b], alT[b]); follower_al_table(hp->ps_A[b], hp->ps_R[b], alT[3 + b]); }
   const double Psm = onepole_lane_power(hp->p_smooth, lane_id());
   // bypass-envelope window of this thread's chunk start, advanced tile by tile without divisions
   // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early (LR4 filters: 2 tiles; the slow transient
@@ -265,17 +276,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
       auto saturate = [&](int b, const float band[C]) {
         // saturateBand, multiband-saturation.js:292-308 (gain 0 dB); the three bands are summed left to right (:345)
         const double drive = P.w_drive[b], bias = P.w_bias[b], bo = P.w_bo[b], mk = P.w_mk[b], mix = P.w_mix[b];
+        float bmx = 0.0f;
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-          if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // keep a few tanh evaluations in flight, not sixteen
-          double e = (k < to_next) ? e_here : e_next;
-          if (base + k >= n) e = 0.0;
-          const double dry = band[k];
-          const double wet = (tanh_fast(drive * (dry + bias)) - bo) * mk;
-          const double sa = e * mix;
-          const double sat = (double)f32r((dry * (1 - sa) + wet * sa) * 1.0);
-          acc[k] = (b == 0) ? sat : acc[k] + sat;
-        }
+        for (int k = 0; k < C; k++) bmx = fmaxf(bmx, fabsf(band[k]));
+        auto body = [&](auto tanh_fn) {
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // keep a few tanh evaluations in flight, not sixteen
+            double e = (k < to_next) ? e_here : e_next;
+            if (base + k >= n) e = 0.0;
+            const double dry = band[k];
+            const double wet = (tanh_fn(drive * (dry + bias)) - bo) * mk;
+            const double sa = e * mix;
+            const double sat = (double)f32r((dry * (1 - sa) + wet * sa) * 1.0);
+            acc[k] = (b == 0) ? sat : acc[k] + sat;
+          }
+        };
+        // |drive (x + bias)| <= 1 for every chunk of the wavefront (drive <= 0.4: bands below ~2.4): the Pade form of tanh
+        if (__all(drive * ((double)bmx + fabs(bias)) <= 1.0)) body([](double z) { return tanh_small(z); });
+        else body([](double z) { return tanh_fast(z); });
       };
       split_chunk(v, pv[1], pv[0], sw, P.w_lp1, P.w_hp1, P.w_lp2, P.w_hp2, slots, saturate);
 #pragma unroll
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
         const AbsView a{ band };
         double fe, se;
         double Sfb = Scar[b], Ssb = Scar[3 + b];                  // (read before the solve's first barrier, stored after its last)
-        follower_solve2(a, fA, fR, Sfb, sA, sR, Ssb, slots.next(), fe, se);
+        follower_solve2(a, fA, fR, Sfb, sA, sR, Ssb, alT[b], alT[3 + b], slots.next(), fe, se);
         if (threadIdx.x == 0) { Scar[b] = Sfb; Scar[3 + b] = Ssb; }
         double u[C];
 #pragma unroll

@@ -50,15 +50,28 @@ __device__ __forceinline__ const T* reload_each_tile(const T* p) {
   return p;
 }
 
-// num / den for operands in a "safe" range (no overflow / underflow / zero of den, |quotient| moderate): v_rcp_f64, two
-// Newton steps, one residual correction of the quotient.  Error <= 1 ulp (the IEEE sequence with div_scale / div_fmas /
-// div_fixup is ~3x the instructions); used only where the result is rounded to f32 further down.
+// num / den for operands in a "safe" range (no overflow / underflow / zero of den, |quotient| moderate): v_rcp_f64 (measured on
+// gfx950: 4.6e-8 relative, tools/probe/rcp_probe.hip), ONE Newton step (2.2e-15), one residual correction of the quotient, which
+// squares what is left: error <= 1 ulp (the IEEE sequence with div_scale / div_fmas / div_fixup is ~3x the instructions); used
+// only where the result is rounded to f32 further down.
 __device__ __forceinline__ double div_fast(double num, double den) {
   double y = __builtin_amdgcn_rcp(den);
   y = fma(fma(-den, y, 1.0), y, y);
-  y = fma(fma(-den, y, 1.0), y, y);
   const double q = num * y;
   return fma(fma(-den, q, num), y, q);
+}
+
+// tanh for |x| <= 1: the [9/8] Pade approximant from the continued fraction x / (1 + x^2 / (3 + x^2 / (5 + ... / 17))), truncation
+// error < 2e-17 on that range, evaluated error <= 2.3e-16 - against ~31 issue slots for tanh_fast (range reduction, a degree-12
+// exponential, a reciprocal) this is 19.  Callers test the range once per chunk and take tanh_fast otherwise.
+__device__ __forceinline__ double tanh_small(double x) {
+  const double y = x * x;
+  double p = 2.9019636862774117676e-8, q = 1.3058836588248352954e-6;
+  p = fma(p, y, 0.000028729440494146376499); q = fma(q, y, 0.00040221216691804927099);
+  p = fma(p, y, 0.0039215686274509803922);   q = fma(q, y, 0.027450980392156862745);
+  p = fma(p, y, 0.13725490196078431373);     q = fma(q, y, 0.47058823529411764706);
+  p = fma(p, y, 1.0);                        q = fma(q, y, 1.0);
+  return div_fast(x * p, q);
 }
 
 // tanh in double, |error| < 2e-15 absolute (the callers add the result to a signal that is then
@@ -499,13 +512,20 @@ __device__ __forceinline__ double follower_solve(const T a[C], double A, double 
   };
   return solve_piecewise(run, S, S, lds);
 }
+// Multiplier table of a follower's chunk maps: tab[p] = A^p R^(C-p), p = 0..C attack steps among the chunk's C (LDS; written by
+// threads 0..C of the workgroup, a barrier before the first use is the caller's).
+__device__ __forceinline__ void follower_al_table(double A, double R, double* tab) {
+  const int p = threadIdx.x;
+  if (p <= C) { double v = 1; for (int i = 0; i < C; i++) v *= (i < p ? A : R); tab[p] = v; }
+}
+
 // Two followers over the same input (the fast and slow envelopes of the transient shaper), solved in one iteration
 // loop: their runs and scans interleave (instruction-level parallelism for the dependent chains) and they share the
 // barriers; the loop ends when both start values reproduce themselves.  lds: 16 doubles.
 // a: the rectified input of the chunk, anything indexable that yields f32 values (an array, or a view that rectifies on the fly)
 template <class T>
 __device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1, double& S1, double A2, double R2, double& S2,
-                                                double* lds, double& start1, double& start2) {
+                                                const double* T1, const double* T2, double* lds, double& start1, double& start2) {
   const int lane = lane_id(), wave = wave_id();
   const double S1_in = S1, S2_in = S2;
   double s1 = S1, s2 = S2;
@@ -559,25 +579,34 @@ __device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1
   }
 #endif
   double p1 = s1, p2 = s2;
-  unsigned pm = 0;                                                // branch pattern of the previous pass, 2 bits per sample
+  unsigned pm1 = 0, pm2 = 0;                                      // branch patterns of the previous pass, one bit per sample
+  // The step e' = (a > e) ? A e + (1 - A) a : R e + (1 - R) a is a + max(A d, R d) with d = e - a when the release is the slower
+  // of the two (R >= A; min otherwise): no compare and no 64-bit select in the pass that only has to find the branch pattern
+  // and the chunk's end value.  The pattern bit IS the sign of d (one v_alignbit per step), the chunk map's multiplier follows
+  // from the number of attack steps alone (T[p] = A^p R^(C-p), a 17-entry LDS table per follower) and its offset from the end
+  // value.  The envelope itself is materialised by the caller with the reference's own expression (follower_step).
+  // (min(x, y) = -max(-x, -y): the sign rides on the two coefficients and on the final fma, so both orders cost the same)
+  const double sg1 = R1 >= A1 ? 1.0 : -1.0, sg2 = R2 >= A2 ? 1.0 : -1.0;
+  const double cA1 = sg1 * A1, cR1 = sg1 * R1, cA2 = sg2 * A2, cR2 = sg2 * R2;
   int it = 0, vp = 0;
   for (; it < 260; it++) {
-    double al1 = 1, be1 = 0, al2 = 1, be2 = 0;
-    unsigned m = 0;
+    double e1 = s1, e2 = s2;
+    unsigned m1 = 0, m2 = 0;
 #pragma unroll
     for (int n = 0; n < C; n++) {
       const double an = (double)a[n];
-      const double e1 = fma(al1, s1, be1), e2 = fma(al2, s2, be2);
-      const bool up1 = an > e1, up2 = an > e2;
-      const double c1 = up1 ? A1 : R1, c2 = up2 ? A2 : R2;
-      m = (m << 2) | ((unsigned)up1 << 1) | (unsigned)up2;
-      be1 = fma(c1, be1 - an, an); be2 = fma(c2, be2 - an, an);
-      al1 = c1 * al1; al2 = c2 * al2;
+      const double d1 = e1 - an, d2 = e2 - an;
+      m1 = __builtin_amdgcn_alignbit(m1, (unsigned)__double2hiint(d1), 31);      // (m << 1) | (d < 0)
+      m2 = __builtin_amdgcn_alignbit(m2, (unsigned)__double2hiint(d2), 31);
+      e1 = fma(sg1, fmax(cA1 * d1, cR1 * d1), an);
+      e2 = fma(sg2, fmax(cA2 * d2, cR2 * d2), an);
     }
     // Same pattern as in the previous pass = same maps = the scan would reproduce the start values this pass ran from:
     // they are the solution, and S1 / S2 already hold the carries of that scan.  (Also the barrier that lets lds be rewritten.)
-    if (it > 0 && !block_any(m != pm, vp)) break;
-    pm = m;
+    if (it > 0 && !block_any(m1 != pm1 || m2 != pm2, vp)) break;
+    pm1 = m1; pm2 = m2;
+    double al1 = T1[__builtin_popcount(m1)], al2 = T2[__builtin_popcount(m2)];
+    double be1 = fma(-al1, s1, e1), be2 = fma(-al2, s2, e2);
 #define WAM_PAIR_STEP(CTRL, RM) { affine_step<CTRL, RM>(al1, be1); affine_step<CTRL, RM>(al2, be2); }
     WAM_PAIR_STEP(0x111, 0xF) WAM_PAIR_STEP(0x112, 0xF) WAM_PAIR_STEP(0x114, 0xF) WAM_PAIR_STEP(0x118, 0xF)
     WAM_PAIR_STEP(0x142, 0xA) WAM_PAIR_STEP(0x143, 0xC)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libwam_hip.so")
+LIB_PATH = os.environ.get("WAM_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libwam_hip.so")   # (override: timing experiments with variant builds)
 
 FP = C.POINTER(C.c_float)
 
