@@ -238,6 +238,11 @@ int wam_parametric_eq(const float* const* ch, int nch, int64_t n, double sample_
                       const double gains_db[5], int cut_mud, float* const* out); /* dsp-worker.js:1222 */
 int wam_exciter(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out);   /* exciter.js:223 */
 int wam_deharsh(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out);   /* dynamic-processor.js:595 ('mastering') */
+/* processHybridDynamic(buffer, preset), dynamic-processor.js:595-609: 'gentle' (:538-549; also what any unknown name and no
+ * name at all select, :604-606), 'aggressive' (:555-566), 'mastering' (:572-585, = wam_deharsh).  The first two are fully wet
+ * (dryWetMix 1.0, :268): samples after the last whole frame fade out with the synthesis window, as the reference's do. */
+enum { WAM_DEHARSH_GENTLE = 0, WAM_DEHARSH_AGGRESSIVE = 1, WAM_DEHARSH_MASTERING = 2 };
+int wam_deharsh_preset(const float* const* ch, int nch, int64_t n, double sample_rate, int preset, float* const* out);
 int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out); /* multiband-saturation.js:365 */
 int wam_multiband_transient(const float* const* ch, int nch, int64_t n, double sample_rate, float* const* out); /* multiband-transient.js:15 */
 

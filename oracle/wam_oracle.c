@@ -656,7 +656,8 @@ static void dft_run(const dft_plan* p, double* out, const double* data, int inv)
  * preset :572-585, process :393-427, _processChannel :444-500, _computeBinGains :319-385,
  * ResonanceDetector.analyze :194-233, GainComputer :75-90, EnvelopeFollower :33-43;
  * FFT wrapper web/lib/dsp/fft.js:41-68; Hann utils.js:98-104 */
-void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* const* out) {
+/* preset: 0 'gentle' (:538-549, the default of processHybridDynamic :595,:604-606), 1 'aggressive' (:555-566), 2 'mastering' */
+void ora_deharsh_preset(const float* const* in, int nch, int64_t n, double sr, int preset, float* const* out) {
   enum { N = 2048, HOP = 512, NB = 1024, NBANDS = 7 };
   static const double lo[NBANDS] = {0, 80, 250, 1000, 3000, 6000, 12000};
   static const double hi[NBANDS] = {80, 250, 1000, 3000, 6000, 12000, 20000};
@@ -667,11 +668,15 @@ void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* c
   static const double knee0[NBANDS] = {10, 8, 6, 6, 4, 3, 6};
   double thr[NBANDS], rat[NBANDS], knee[NBANDS], ks[NBANDS], ke[NBANDS], ac[NBANDS], rcf[NBANDS];
   for (int b = 0; b < NBANDS; b++) {
-    thr[b] = thr0[b] + 12; knee[b] = knee0[b] + 8; rat[b] = fmax(1.2, rat0[b] - 1.5);
+    if (preset == 2) { thr[b] = thr0[b] + 12; knee[b] = knee0[b] + 8; rat[b] = fmax(1.2, rat0[b] - 1.5); }
+    else if (preset == 1) { thr[b] = thr0[b] - 6; knee[b] = knee0[b]; rat[b] = rat0[b] + 2; }
+    else { thr[b] = thr0[b] + 6; knee[b] = knee0[b]; rat[b] = fmax(2, rat0[b] - 1); }
     ks[b] = thr[b] - knee[b] / 2; ke[b] = thr[b] + knee[b] / 2;
     ac[b] = exp(-1 / (sr * att[b] / 1000)); rcf[b] = exp(-1 / (sr * rel[b] / 1000));
   }
-  const double mix = 0.15, sens = 0.2, maxcut = -3;
+  /* constructor defaults :268-276 (dryWetMix 1.0, aiArtifactMode true) under what each preset sets */
+  const double mix = preset == 2 ? 0.15 : 1.0, sens = preset == 2 ? 0.2 : preset == 1 ? 0.8 : 0.3, maxcut = preset == 2 ? -3 : preset == 1 ? -18 : -6;
+  const int ai = preset != 2;
   float window[N];
   for (int i = 0; i < N; i++) window[i] = F32(0.5 * (1 - cos(2 * M_PI * i / (N - 1))));
   int band_of[NB];
@@ -731,6 +736,7 @@ void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* c
       for (int b = 0; b < NB; b++) {
         double gdb = bg[band_of[b]];
         if (res[b] > 0) { const double cut = maxcut * (double)res[b] * sens; gdb += cut; }
+        if (ai) { const double fq = b * sr / N; if (fq >= 5000 && fq <= 12000) gdb += gdb * 0.3; }           /* :375-378 */
         gains[b] = F32(db_to_linear(gdb));
       }
       for (int b = 0; b < NB; b++) {
@@ -744,10 +750,11 @@ void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* c
       }
     }
     for (int64_t i = 0; i < n; i++) o[i] = F32((double)o[i] / 4.0);
-    for (int64_t i = 0; i < n; i++) o[i] = F32((double)in[c][i] * (1 - mix) + (double)o[i] * mix);
+    if (mix < 1) for (int64_t i = 0; i < n; i++) o[i] = F32((double)in[c][i] * (1 - mix) + (double)o[i] * mix);   /* :419-423 */
   }
   free(tin); free(spec); free(inv); dft_free(plan);
 }
+void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* const* out) { ora_deharsh_preset(in, nch, n, sr, 2, out); }
 
 /* ref: web/lib/dsp/multiband-saturation.js:365-368 applyTapeWarmth: process :320-355,
  * createBypassEnvelope :204-269, saturateBand :280-311, splitBands :125-148, preset :27-36 */

@@ -60,6 +60,7 @@ void ora_normalize(const float* const* in, int nch, int64_t n, double sr, double
                    float* const* out, wam_normalize_result* res);
 void ora_exciter(const float* const* in, int nch, int64_t n, double sr, float* const* out);
 void ora_deharsh(const float* const* in, int nch, int64_t n, double sr, float* const* out);
+void ora_deharsh_preset(const float* const* in, int nch, int64_t n, double sr, int preset, float* const* out);   /* 0 gentle, 1 aggressive, 2 mastering */
 void ora_warmth(const float* const* in, int nch, int64_t n, double sr, float* const* out);
 void ora_punch(const float* const* in, int nch, int64_t n, double sr, float* const* out);
 void ora_pcm24(const float* const* in, int nch, int64_t n, uint8_t* out);

@@ -5,6 +5,7 @@
 //   * the look-ahead limiter, the soft clipper and the chain at 176.4 / 192 kHz (dsp-worker.js:299-309: 3 ms look-ahead
 //     = 576 samples, 10 ms RMS window = 1920 samples at 192 kHz);
 //   * the PROGRESS streams of the NORMALIZE and APPLY_LIMITER messages (dsp-worker.js:458,471,491 and :302,364,427,448).
+//   * processHybridDynamic's 'gentle' and 'aggressive' presets (dynamic-processor.js:538-566; substitute DFT as in gen_golden.mjs);
 //   node tests/golden/gen_shapes.mjs      (needs /root/reference; nothing of it is written into the repo)
 import fs from 'fs';
 import path from 'path';
@@ -116,6 +117,17 @@ async function main() {
     const mono = synthTrack(32, 1, n, sr, { amp: 2.4, clickAmp: 0.9 });
     const rm = await send('APPLY_LIMITER', { channels: cloneChans(mono), sampleRate: sr });
     cases.msg_limiter_mono_defaults = { kind: 'limiter', idx: 32, nch: 1, sr, n, opts: { amp: 2.4, clickAmp: 0.9 }, ceiling_lin: 0.891, progress: rm.progress, out: saveChans('shapes.msg_limiter_mono', rm.result.channels) };
+  }
+  // ---- processHybridDynamic presets other than the chain's 'mastering' (fully wet: the tail after the last frame fades to zero)
+  for (const c of [{ name: 'deharsh_gentle', preset: 'gentle', idx: 50, nch: 2, sr: 48000, n: 30000, opts: { amp: 1.8, clickAmp: 0.7 } },
+    { name: 'deharsh_aggressive', preset: 'aggressive', idx: 50, nch: 2, sr: 48000, n: 30000, opts: { amp: 1.8, clickAmp: 0.7 } },
+    { name: 'deharsh_gentle_mono44', preset: 'gentle', idx: 51, nch: 1, sr: 44100, n: 20000, opts: { amp: 0.6 } },
+    { name: 'deharsh_aggressive_mono44', preset: 'aggressive', idx: 51, nch: 1, sr: 44100, n: 20000, opts: { amp: 0.6 } },
+    { name: 'deharsh_default_short', preset: undefined, idx: 52, nch: 2, sr: 48000, n: 2500, opts: {} }]) {     // one frame... none: floor((n - 2048) / 512) = 0
+    const x = synthTrack(c.idx, c.nch, c.n, c.sr, c.opts);
+    const y = c.preset === undefined ? lib.processHybridDynamic(toAB(x, c.sr)) : lib.processHybridDynamic(toAB(x, c.sr), c.preset);
+    cases[c.name] = { kind: 'deharsh', preset: c.preset === undefined ? null : c.preset, idx: c.idx, nch: c.nch, sr: c.sr, n: c.n, opts: c.opts, dft: 'substitute',
+      out: saveChans('shapes.' + c.name, chansOf(y)) };
   }
   console.log = log;
   fs.writeFileSync(path.join(OUT, 'shapes.json'), JSON.stringify({ generator: 'tests/golden/gen_shapes.mjs', node: process.version, cases }, null, 1));

@@ -201,6 +201,16 @@ async function gpu() {
       ok(Math.abs(wam.measureLUFS(ab) - c.lufs) <= 0.01 && Math.abs(wam.findTruePeak(ab) - c.tp_db) <= 0.01, `${name} through the JS surface`);
       ok(Math.abs(wam.measureShortTermLUFS(ab, c.short_term[1][0]) - c.short_term[1][1]) <= 0.01, `${name} short-term`);
     } }
+  // processHybridDynamic presets (dynamic-processor.js:595-607): named, unnamed (= 'gentle') and unknown (= 'gentle')
+  { const SH = JSON.parse(fs.readFileSync(path.join(DATA, 'shapes.json'), 'utf8')).cases;
+    for (const name of ['deharsh_gentle', 'deharsh_aggressive', 'deharsh_aggressive_mono44']) {
+      const c = SH[name]; const y = wam.processHybridDynamic(track(c), c.preset);
+      ok(maxAbsDiff(y.getChannelData(0), f32(c.out[0])) <= 1e-5, `${name} vs reference golden`);
+    }
+    const c = SH['deharsh_gentle'];
+    ok(maxAbsDiff(wam.processHybridDynamic(track(c)).getChannelData(1), f32(c.out[1])) <= 1e-5, 'no preset = gentle');
+    ok(maxAbsDiff(wam.processHybridDynamic(track(c), 'nope').getChannelData(1), f32(c.out[1])) <= 1e-5, 'unknown preset = gentle');
+    ok(maxAbsDiff(wam.processHybridDynamic(track(c), 'mastering').getChannelData(1), f32(c.out[1])) > 1e-3, 'mastering differs from gentle'); }
   // multi-device batch: two entries on device 0, three tracks - each track equals its single render bit for bit
   { const c = golden['chain_core_1s'];
     const abs = [0, 1, 2].map((k) => track(Object.assign({}, c, { idx: c.idx + k })));

@@ -254,8 +254,12 @@ def exciter(chans, sr):
     return _simple(lib().ora_exciter)(chans, sr)
 
 
-def deharsh(chans, sr):
-    return _simple(lib().ora_deharsh)(chans, sr)
+DEHARSH_PRESETS = {"gentle": 0, "aggressive": 1, "mastering": 2}     # any other name is 'gentle' (dynamic-processor.js:604-606)
+
+
+def deharsh(chans, sr, preset="mastering"):
+    return _run_stage(lib().ora_deharsh_preset, chans,
+                      lambda n: (C.c_int(len(chans)), C.c_int64(n), C.c_double(sr), C.c_int(DEHARSH_PRESETS.get(preset, 0))))
 
 
 def warmth(chans, sr):

@@ -9,8 +9,8 @@ x = O.synth(60, 2, n, sr, {"amp": 1.8, "clickAmp": 0.7})
 yo = O.deharsh(x, sr)
 for exact in (0, 1):
     wam.tune("dh_exact", exact)
-    y = wam.process_hybrid_dynamic(x, sr)
-    t0 = time.perf_counter(); y = wam.process_hybrid_dynamic(x, sr); dt = time.perf_counter() - t0
+    y = wam.process_hybrid_dynamic(x, sr, "mastering")
+    t0 = time.perf_counter(); y = wam.process_hybrid_dynamic(x, sr, "mastering"); dt = time.perf_counter() - t0
     for c in range(2):
         d = np.abs(y[c].astype(np.float64) - yo[c])
         ulp = np.spacing(np.abs(yo[c]).astype(np.float32)).astype(np.float64)
@@ -27,7 +27,7 @@ wam.tune("dh_exact", 0)
 # the scan-based band sums against the serial walk: must be the same bits
 for sr2, seed in ((48000, 61), (44100, 62), (96000, 63), (16000, 64)):
     x2 = O.synth(seed, 2, sr2 * 6, sr2, {"amp": 1.5, "clickAmp": 0.7, "quietFrom": sr2 * 2, "quietTo": sr2 * 3, "quietGain": 0.0})
-    wam.tune("dh_scan_sums", 0); y0 = wam.process_hybrid_dynamic(x2, sr2)
-    wam.tune("dh_scan_sums", 1); y1 = wam.process_hybrid_dynamic(x2, sr2)
+    wam.tune("dh_scan_sums", 0); y0 = wam.process_hybrid_dynamic(x2, sr2, "mastering")
+    wam.tune("dh_scan_sums", 1); y1 = wam.process_hybrid_dynamic(x2, sr2, "mastering")
     print(f"scan sums vs serial walk at {sr2} Hz: identical = {all(np.array_equal(p, q) for p, q in zip(y0, y1))}")
 wam.tune("reset")

@@ -214,7 +214,7 @@ def test_ragged_fx_and_chain(n, nch):
     assert maxerr(wam.apply_exciter(x, sr), O.exciter(x, sr)) <= PCM_TOL
     assert maxerr(wam.apply_tape_warmth(x, sr), O.warmth(x, sr)) <= PCM_TOL
     assert maxerr(wam.apply_multiband_transient(x, sr), O.punch(x, sr)) <= PCM_TOL
-    assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= PCM_TOL
+    assert maxerr(wam.process_hybrid_dynamic(x, sr, "mastering"), O.deharsh(x, sr)) <= PCM_TOL
     s = dict(wam.DEFAULT_SETTINGS, deharsh=True, glueCompression=True, eqLow=1, eqHigh=2, cutMud=True)
     y, res = wam.render_full_chain(x, sr, s, "export")
     yo, ro = O.render_chain(x, sr, s, "export")
@@ -231,7 +231,7 @@ def test_empty_input_everywhere():
                wam.apply_mastering_soft_clip):
         out = fn(z, sr)
         assert len(out) == 2 and len(out[0]) == 0
-    assert len(wam.process_hybrid_dynamic(z, sr)[0]) == 0
+    assert len(wam.process_hybrid_dynamic(z, sr, "mastering")[0]) == 0
     y, res = wam.render_full_chain(z, sr, dict(wam.DEFAULT_SETTINGS), "export")
     assert len(y[0]) == 0
     assert wam.measure_lufs(z, sr) == -14.0 and wam.find_true_peak(z) == float("-inf")

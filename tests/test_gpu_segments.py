@@ -39,12 +39,12 @@ def test_deharsh_segments(hot, exact):
     ref = O.deharsh(x, sr)
     wam.tune("dh_exact", exact)                # exact kernels: the warm-up is raised to 96 frames whatever the knob says
     wam.tune("dh_seg_frames", 1 << 20)
-    whole = wam.process_hybrid_dynamic(x, sr)
+    whole = wam.process_hybrid_dynamic(x, sr, "mastering")
     assert maxerr(whole, ref) <= TOL
     for seg, warm in ((16, 48), (7, 40), (64, 48)):
         wam.tune("dh_seg_frames", seg)
         wam.tune("dh_warm_frames", warm)
-        y = wam.process_hybrid_dynamic(x, sr)
+        y = wam.process_hybrid_dynamic(x, sr, "mastering")
         assert maxerr(y, ref) <= TOL
         assert maxerr(y, whole) <= SEAM_TOL
 

@@ -154,3 +154,32 @@ def test_normalize_and_limiter_message_streams():
         c = S["msg_limiter"]
         x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
         wam.apply_lookahead_limiter(x, c["sr"], c["ceiling_lin"], on_progress=lambda p, s: p >= 0.3)
+
+
+@pytest.mark.parametrize("name", [k for k, c in S.items() if c["kind"] == "deharsh"])
+def test_deharsh_presets_vs_reference(name):
+    """processHybridDynamic 'gentle' / 'aggressive' / no preset (dynamic-processor.js:538-566, :595-607) against the reference's
+    output (made with the substitute DFT: unpinned at the fft.js boundary) and, longer and across segment boundaries, the oracle."""
+    c = S[name]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    y = wam.process_hybrid_dynamic(x, c["sr"], c["preset"]) if c["preset"] else wam.process_hybrid_dynamic(x, c["sr"])
+    assert maxerr(y, G.chans(c["out"])) <= PCM_TOL
+
+
+@pytest.mark.parametrize("preset", ["gentle", "aggressive", "no-such-preset"])
+def test_deharsh_presets_segments_vs_oracle(preset):
+    sr, n = 48000, 48000 * 5 + 777
+    x = O.synth(61, 2, n, sr, {"amp": 1.8, "clickAmp": 0.7})
+    yo = O.deharsh(x, sr, preset)
+    assert maxerr(O.deharsh(x, sr, "gentle"), O.deharsh(x, sr, "aggressive")) > 1e-2       # the presets do differ on this signal
+    try:
+        for seg in (0, 16, 50):
+            wam.tune("dh_seg_frames", seg)
+            y = wam.process_hybrid_dynamic(x, sr, preset)
+            assert maxerr(y, yo) <= PCM_TOL, seg
+    finally:
+        wam.tune("reset")
+    # fully wet: nothing after the last frame's end ((F - 1) hop + N) survives, the input does not leak through
+    F = (n - 2048) // 512
+    end = (F - 1) * 512 + 2048
+    assert end < n and all(np.all(ch[end:] == 0) for ch in y)

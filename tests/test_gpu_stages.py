@@ -132,9 +132,9 @@ def dh_mode(request):
 @pytest.mark.skipif(not has("wam_deharsh"), reason="not built")
 def test_deharsh(golden, clip, dh_mode):
     sr, x = clip
-    assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= TOL
+    assert maxerr(wam.process_hybrid_dynamic(x, sr, "mastering"), O.deharsh(x, sr)) <= TOL
     S = golden["stages_hot"]["stages"]   # golden made with a substitute DFT: parity unpinned at the fft.js boundary
-    assert maxerr(wam.process_hybrid_dynamic(stage_in(golden, "dc"), 48000), G.chans(S["deharsh"]["out"])) <= TOL
+    assert maxerr(wam.process_hybrid_dynamic(stage_in(golden, "dc"), 48000, "mastering"), G.chans(S["deharsh"]["out"])) <= TOL
 
 
 @pytest.mark.skipif(not has("wam_deharsh"), reason="not built")
@@ -150,7 +150,7 @@ def test_deharsh_exact_share():
     try:
         for exact, share, worst in ((1, 0.999, 1.2e-7), (0, 0.85, 2.5e-7)):
             wam.tune("dh_exact", exact)
-            y = wam.process_hybrid_dynamic(x, sr)
+            y = wam.process_hybrid_dynamic(x, sr, "mastering")
             d = np.concatenate([np.abs(a.astype(np.float64) - b) for a, b in zip(y, yo)])
             assert (d == 0).mean() >= share and d.max() <= worst, (exact, (d == 0).mean(), d.max())
     finally:
@@ -202,9 +202,9 @@ def test_deharsh_band_sums_scan_equals_serial_walk(sr):
         c[3 * sr:4 * sr] *= np.float32(3e-8)
     try:
         wam.tune("dh_scan_sums", 0)
-        y0 = wam.process_hybrid_dynamic(x, sr)
+        y0 = wam.process_hybrid_dynamic(x, sr, "mastering")
         wam.tune("dh_scan_sums", 1)
-        y1 = wam.process_hybrid_dynamic(x, sr)
+        y1 = wam.process_hybrid_dynamic(x, sr, "mastering")
     finally:
         wam.tune("reset")
     assert all(np.array_equal(a, b) for a, b in zip(y0, y1))
@@ -216,7 +216,7 @@ def test_deharsh_rates_and_shapes(sr, n, nch, dh_mode):
     """De-harsh at other sample rates (band edges move), odd lengths (channel 1 is then not 8-byte aligned: the scalar load path),
     mono, and lengths around one frame (no frame at all / exactly one)."""
     x = O.synth(13, nch, n, sr, {"amp": 2.0, "clickAmp": 0.6})
-    assert maxerr(wam.process_hybrid_dynamic(x, sr), O.deharsh(x, sr)) <= TOL
+    assert maxerr(wam.process_hybrid_dynamic(x, sr, "mastering"), O.deharsh(x, sr)) <= TOL
 
 
 def test_analyze_on_load():

@@ -79,3 +79,12 @@ def test_normalize_and_limiter_messages():
         c = S[name]
         x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
         same(O.limiter(x, c["sr"], c["ceiling_lin"]), G.chans(c["out"]))
+
+
+@pytest.mark.parametrize("name", [k for k, c in S.items() if c["kind"] == "deharsh"])
+def test_deharsh_presets(name):
+    """processHybridDynamic 'gentle' / 'aggressive' / no preset given (dynamic-processor.js:538-566, :595-607).  Substitute DFT on
+    both sides as in test_oracle_golden.py: unpinned at the fft.js boundary, bit-exact everywhere else."""
+    c = S[name]
+    x = O.synth(c["idx"], c["nch"], c["n"], c["sr"], c["opts"])
+    same(O.deharsh(x, c["sr"], c["preset"] or "gentle"), G.chans(c["out"]))

@@ -64,7 +64,8 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
                        const float* env, double pre_gain, double sr, hipStream_t s);
 void make_heavy_plan(double sr, int64_t n, HeavyPlan* p);
-int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n, double sr, double pre_gain, hipStream_t s);
+int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n, double sr, double pre_gain, hipStream_t s,
+                    int preset = WAM_DEHARSH_MASTERING);
 
 void make_front_plan(double sr, int do_hpf, int do_lpf, const double* eq_gains, int cut_mud,
                      int do_glue, double glue_thr_db, double glue_ratio, double glue_attack, double glue_release,

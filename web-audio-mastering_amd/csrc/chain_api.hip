@@ -432,14 +432,16 @@ static int run_heavy(const float* const* ch, int nch, int64_t n, double sr, int 
   return st.down(st.out.as<float>(), out, nullptr);
 }
 
-int wam_deharsh(const float* const* ch, int nch, int64_t n, double sr, float* const* out) {
+int wam_deharsh_preset(const float* const* ch, int nch, int64_t n, double sr, int preset, float* const* out) {
   int rc = check_io(ch, nch, n, out); if (rc) return rc;
   if (!(sr > 0)) { set_error("invalid sample rate"); return WAM_ERR_INVALID; }
+  if (preset != WAM_DEHARSH_GENTLE && preset != WAM_DEHARSH_AGGRESSIVE && preset != WAM_DEHARSH_MASTERING) { set_error("unknown de-harsh preset"); return WAM_ERR_INVALID; }
   rc = ensure_device(); if (rc) return rc;
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
-  rc = enqueue_deharsh(st.in.as<float>(), st.out.as<float>(), 1, nch, n, sr, 1.0, nullptr); if (rc) return rc;
+  rc = enqueue_deharsh(st.in.as<float>(), st.out.as<float>(), 1, nch, n, sr, 1.0, nullptr, preset); if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }
+int wam_deharsh(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return wam_deharsh_preset(ch, nch, n, sr, WAM_DEHARSH_MASTERING, out); }
 
 int wam_exciter(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 0, out); }
 int wam_tape_warmth(const float* const* ch, int nch, int64_t n, double sr, float* const* out) { return run_heavy(ch, nch, n, sr, 1, out); }

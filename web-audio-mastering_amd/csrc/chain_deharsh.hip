@@ -27,6 +27,9 @@ struct DeharshPlan {
   int64_t nframes;
   int band_start[kBands + 1];    // band b = bins [band_start[b], band_start[b + 1]) (the bands are ascending frequency ranges)
   uint8_t band_of[kBins];
+  // what the presets other than 'mastering' vary (the mastering kernels carry its values as constants):
+  double max_cut, sens, mix;     // dynamicEqMaxCut, dynamicEqSensitivity, dryWetMix (:268-273)
+  int ai_lo, ai_hi;              // aiArtifactMode: bins with 5000 <= freq <= 12000 (:375), empty range when off
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -872,6 +875,9 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   }
 }
 
+// GEN = false: the 'mastering' preset of the export chain, its constants folded.  GEN = true: max cut, sensitivity, the AI-artifact
+// range and the dry/wet mix come from the plan ('gentle', 'aggressive': fully wet, so there is no mix step at all, :419).
+template <bool GEN>
 __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                        const DeharshPlan* __restrict__ dp, const dcx* __restrict__ twd,
                                                        const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
@@ -886,13 +892,17 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   const float* x = in + chan * n;
   float* y = out + chan * n;
   const int lane = lane_id(), wave = wave_id();
-  const double dry = 1 - 0.15, wetm = 0.15;
+  const double wetm = GEN ? P.mix : 0.15, dry = 1 - wetm;
+  const bool mixed = !GEN || wetm < 1;
   const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
   if (seg >= nseg) return;
   auto load_in = [&](int64_t s) -> float {
     float v = (s < n) ? x[s] : 0.0f;
     if (pre_gain != 1.0) v = f32r((double)v * pre_gain);
     return v;
+  };
+  auto mix_out = [&](int64_t s, float wet) -> float {              // :419-423
+    return mixed ? f32r((double)load_in(s) * dry + (double)wet * wetm) : wet;
   };
   const int64_t F = P.nframes;
   const int64_t f0 = seg * seg_frames;
@@ -933,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     for (int j = 0; j < 16; j++) zw[wave_out_index_d(ob, j)] = v[j];
     wave_sync();
     // ResonanceDetector.analyze (:194-233) and the gain of one bin (:361-382), with the reference's Float32Array stores
-    auto bin_gain = [&](float mag, float& av_state, int band) -> double {
+    auto bin_gain = [&](float mag, float& av_state, int band, int bin) -> double {
       float res = 0.0f;
       if (first) av_state = mag;
       else {
@@ -942,7 +952,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, (div_fast((double)mag, av) - 1.5) / 2));
       }
       double gdb = bg[band];
-      if (res > 0) gdb += -3.0 * (double)res * 0.2;
+      if (res > 0) gdb += GEN ? P.max_cut * (double)res * P.sens : -3.0 * (double)res * 0.2;        // :369-372
+      if (GEN && bin >= P.ai_lo && bin <= P.ai_hi) gdb += gdb * 0.3;                                 // :375-378
       return (double)f32r(exp_fast(gdb * (2.30258509299404568402 / 20)));   // 10^(gdb / 20) (a division by 20 would be a full IEEE
                                                                             // sequence per bin); gains is a Float32Array (:320,:381)
     };
@@ -954,8 +965,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       if (j == 0 && k == 0) {
         const dcx z0 = zw[0], zh = zw[512];
         const double x0 = z0.x + z0.y, xny = z0.x - z0.y;         // X[0] and X[1024] are real; the Nyquist bin is not scaled
-        const double g0 = bin_gain(f32r(fabs(x0)), avg[0], bk);
-        const double gh = bin_gain(mag_f32(zh), avg[1], bm);
+        const double g0 = bin_gain(f32r(fabs(x0)), avg[0], bk, 0);
+        const double gh = bin_gain(mag_f32(zh), avg[1], bm, 512);
         if (synth) {
           const double y0 = x0 * g0;
           zw[0] = dcx{ 0.5 * (y0 + xny), 0.5 * (y0 - xny) };
@@ -966,8 +977,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         const dcx wtw = twB[k];
         const BinPairD p = split_pair_d(zk, zm, wtw);
         const dcx xk{ p.xe.x + p.t.x, p.xe.y + p.t.y }, xmc{ p.xe.x - p.t.x, p.xe.y - p.t.y };
-        const double gk = bin_gain(mag_f32(xk), avg[2 * j], bk);
-        const double gm = bin_gain(mag_f32(xmc), avg[2 * j + 1], bm);
+        const double gk = bin_gain(mag_f32(xk), avg[2 * j], bk, k);
+        const double gm = bin_gain(mag_f32(xmc), avg[2 * j + 1], bm, kM - k);
         if (synth) {
           const dcx yk{ xk.x * gk, xk.y * gk }, ymc{ xmc.x * gm, xmc.y * gm };
           const dcx ye{ 0.5 * (yk.x + ymc.x), 0.5 * (yk.y + ymc.y) };
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       if ((j >> 3) == jdone) {
         if (f >= f0) {
           const int64_t s = pos + i;
-          y[s] = f32r((double)load_in(s) * dry + (double)f32r((double)acc[j] / 4.0) * wetm);
+          y[s] = mix_out(s, f32r((double)acc[j] / 4.0));
         }
         acc[j] = 0.0f;
       }
@@ -1023,18 +1034,21 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   for (int64_t s = done + lane; s < n; s += 64) {
     float w = 0.0f;
     if (s < ring_end) w = f32r((double)ring[(int)(s & (kN - 1))] / 4.0);
-    y[s] = f32r((double)load_in(s) * dry + (double)w * wetm);
+    y[s] = mix_out(s, w);
   }
 }
 
 // ---------------------------------------------------------------------------- host
-static void make_deharsh_plan(double sr, int64_t n, DeharshPlan* p) {
+static void make_deharsh_plan(double sr, int64_t n, int preset, DeharshPlan* p) {
   std::memset(p, 0, sizeof(*p));
   static const double lo[kBands] = {0, 80, 250, 1000, 3000, 6000, 12000}, hi[kBands] = {80, 250, 1000, 3000, 6000, 12000, 20000};
   static const double att[kBands] = {30, 20, 10, 8, 2, 2, 5}, rel[kBands] = {200, 150, 100, 80, 40, 30, 50};
   static const double thr0[kBands] = {-12, -15, -18, -20, -26, -28, -22}, rat0[kBands] = {2, 2.5, 3, 3.5, 5, 6, 3}, knee0[kBands] = {10, 8, 6, 6, 4, 3, 6};
-  for (int b = 0; b < kBands; b++) {            // createMasteringPreset, dynamic-processor.js:572-585
-    p->thr[b] = thr0[b] + 12; p->knee[b] = knee0[b] + 8; p->ratio[b] = std::fmax(1.2, rat0[b] - 1.5);
+  const bool mastering = preset == WAM_DEHARSH_MASTERING, aggressive = preset == WAM_DEHARSH_AGGRESSIVE;
+  for (int b = 0; b < kBands; b++) {            // createMasteringPreset :572-585, createAggressivePreset :555-566, createGentlePreset :538-549
+    if (mastering) { p->thr[b] = thr0[b] + 12; p->knee[b] = knee0[b] + 8; p->ratio[b] = std::fmax(1.2, rat0[b] - 1.5); }
+    else if (aggressive) { p->thr[b] = thr0[b] - 6; p->knee[b] = knee0[b]; p->ratio[b] = rat0[b] + 2; }
+    else { p->thr[b] = thr0[b] + 6; p->knee[b] = knee0[b]; p->ratio[b] = std::fmax(2.0, rat0[b] - 1); }
     p->ks[b] = p->thr[b] - p->knee[b] / 2; p->ke[b] = p->thr[b] + p->knee[b] / 2;
     p->A[b] = std::exp(-1 / (sr * att[b] / 1000)); p->R[b] = std::exp(-1 / (sr * rel[b] / 1000));
   }
@@ -1048,11 +1062,20 @@ static void make_deharsh_plan(double sr, int64_t n, DeharshPlan* p) {
   for (int k = kBins - 1; k >= 0; k--) p->band_start[p->band_of[k]] = k;        // first bin of every band that has bins
   for (int b = kBands - 1; b >= 0; b--) if (p->band_start[b] > p->band_start[b + 1]) p->band_start[b] = p->band_start[b + 1];   // empty bands
   p->nframes = n >= kN ? (int64_t)std::floor((double)(n - kN) / kHop) : 0;    // :445
+  p->max_cut = mastering ? -3 : aggressive ? -18 : -6;
+  p->sens = mastering ? 0.2 : aggressive ? 0.8 : 0.3;
+  p->mix = mastering ? 0.15 : 1.0;                                            // constructor default :268
+  p->ai_lo = 1; p->ai_hi = 0;
+  if (!mastering) {                                                           // aiArtifactMode (default true :276): an interval of bins
+    p->ai_lo = kBins; p->ai_hi = -1;
+    for (int k = 0; k < kBins; k++) { const double fr = k * sr / kN; if (fr >= 5000 && fr <= 12000) { if (k < p->ai_lo) p->ai_lo = k; p->ai_hi = k; } }
+  }
 }
 
-int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n, double sr, double pre_gain, hipStream_t s) {
+int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n, double sr, double pre_gain, hipStream_t s, int preset) {
   if (n <= 0) return WAM_OK;
-  DeharshPlan dp; make_deharsh_plan(sr, n, &dp);
+  const bool mastering = preset == WAM_DEHARSH_MASTERING;
+  DeharshPlan dp; make_deharsh_plan(sr, n, preset, &dp);
   const int nchan = ntracks * nch;
   const size_t nf = (size_t)(dp.nframes > 0 ? dp.nframes : 1);
   // per-call device scratch (freed after the stream has consumed it)
@@ -1073,7 +1096,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
-  const bool exact = tuning().dh_exact != 0;
+  const bool exact = tuning().dh_exact != 0 || !mastering;     // fully wet presets: nothing scales the float32 transform's rounding down
   DevBuf twd;
   if (exact) {                                     // double tables: twl[15][64] lane-major, twq[4][16], twB[513]
     std::vector<dcx> td(kTwl + kTwq + kTwB);
@@ -1103,7 +1126,9 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   const int64_t warm = exact && tuning().dh_warm_frames < 96 ? 96 : tuning().dh_warm_frames;
   const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, exact ? 8192 : 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
-  if (exact) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
+  if (exact && mastering) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x<false>, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
+                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm, win_sym);
+  else if (exact) WAM_LAUNCH("k_dh_apply_xg", k_dh_apply_x<true>, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
                         (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm, win_sym);
   else WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                   winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);

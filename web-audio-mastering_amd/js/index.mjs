@@ -110,8 +110,8 @@ export function applyFinalFilters(audioBuffer, options = {}) {                  
   return stage('finalFilters', audioBuffer, [highpass ? 1 : 0, lowpass ? 1 : 0]);
 }
 export function processHybridDynamic(audioBuffer, preset = 'gentle') {               // dynamic-processor.js:595
-  if (preset !== 'mastering') throw new Error(`wam: only the 'mastering' preset (the export chain's) is implemented, got '${preset}'`);
-  return stage('deharsh', audioBuffer);
+  const id = { gentle: 0, aggressive: 1, mastering: 2 }[preset];                      // any other name is 'gentle' (:604-606)
+  return stage('deharsh', audioBuffer, [id === undefined ? 0 : id]);
 }
 export function applyExciter(audioBuffer) { return stage('exciter', audioBuffer); }                     // exciter.js:223
 export function applyTapeWarmth(audioBuffer) { return stage('tapeWarmth', audioBuffer); }               // multiband-saturation.js:365

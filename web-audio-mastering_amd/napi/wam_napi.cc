@@ -247,7 +247,7 @@ Job* job_stage(napi_env env, napi_value* a) {
     if (nm == "stereo") return wam_stereo(p.data(), j.in.n, sr, q[0], q[1] != 0, q[2], o.data());
     if (nm == "eq") return wam_parametric_eq(p.data(), nch, j.in.n, sr, q, q[5] != 0, o.data());
     if (nm == "exciter") return wam_exciter(p.data(), nch, j.in.n, sr, o.data());
-    if (nm == "deharsh") return wam_deharsh(p.data(), nch, j.in.n, sr, o.data());
+    if (nm == "deharsh") return wam_deharsh_preset(p.data(), nch, j.in.n, sr, (int)q[0], o.data());
     if (nm == "tapeWarmth") return wam_tape_warmth(p.data(), nch, j.in.n, sr, o.data());
     if (nm == "multibandTransient") return wam_multiband_transient(p.data(), nch, j.in.n, sr, o.data());
     if (nm == "gain") return wam_apply_gain(p.data(), nch, j.in.n, q[0], o.data());

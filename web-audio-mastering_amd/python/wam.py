@@ -296,8 +296,13 @@ def apply_exciter(chans, sr):
     return _stage(lib().wam_exciter, chans, C.c_double(sr))
 
 
-def process_hybrid_dynamic(chans, sr):
-    return _stage(lib().wam_deharsh, chans, C.c_double(sr))
+DEHARSH_PRESETS = {"gentle": 0, "aggressive": 1, "mastering": 2}
+
+
+def process_hybrid_dynamic(chans, sr, preset="gentle"):
+    """processHybridDynamic(buffer, preset = 'gentle'), dynamic-processor.js:595-609 (an unknown name is 'gentle', :604-606);
+    the export chain's stage is preset='mastering'."""
+    return _stage(lib().wam_deharsh_preset, chans, C.c_double(sr), C.c_int(DEHARSH_PRESETS.get(preset, 0)))
 
 
 def apply_tape_warmth(chans, sr):
