@@ -187,13 +187,12 @@ def test_limiter_lib_twin():
     assert maxerr(a, b) > 1e-4                 # the twins do differ where the soft-knee pass engages
 
 
-@pytest.mark.skipif(not has("wam_deharsh"), reason="not built")
-@pytest.mark.parametrize("sr", [16000, 44100, 48000, 96000])
-def test_deharsh_band_sums_scan_equals_serial_walk(sr):
-    """The default de-harsh kernels form the reference's sequential f32 band sums with wavefront scans plus a walk over the sum's
-    binade crossings, verified per frame, and fall back to the bin-by-bin walk otherwise (csrc/chain_deharsh.hip,
-    band_energies_scan).  Both must give the same bits: hot material, a stretch of digital silence (zero sums: fallback), a
-    stretch at -400 dB (f32-denormal energies: fallback) and one at -150 dB (tiny but normal), all within one input."""
+@pytest.mark.parametrize("sr", [48000, 44100, 16000])
+def test_deharsh_band_sums_over_silence_and_denormals(sr):
+    """The default de-harsh kernels form the reference's sequential f32 band sums by walking every frame's magnitudes bin by bin,
+    one lane per frame (csrc/chain_deharsh.hip, k_dh_bandsum), from a scratch array that a large batch fills in groups of
+    channels.  Hot material, a stretch of digital silence (zero sums), a stretch at -400 dB (f32-denormal energies) and one at
+    -150 dB (tiny but normal) within one input; the grouping (scratch for one channel at a time) must not change a bit."""
     n = sr * 5
     x = [c.copy() for c in O.synth(61, 2, n, sr, {"amp": 1.7, "clickAmp": 0.7})]
     for c in x:
@@ -201,14 +200,19 @@ def test_deharsh_band_sums_scan_equals_serial_walk(sr):
         c[2 * sr:3 * sr] *= np.float32(1e-20)
         c[3 * sr:4 * sr] *= np.float32(3e-8)
     try:
-        wam.tune("dh_scan_sums", 0)
-        y0 = wam.process_hybrid_dynamic(x, sr, "mastering")
-        wam.tune("dh_scan_sums", 1)
         y1 = wam.process_hybrid_dynamic(x, sr, "mastering")
+        wam.tune("dh_mag_bytes", 4096 * ((n - 2048) // 512))          # one channel's frames: two groups
+        y0 = wam.process_hybrid_dynamic(x, sr, "mastering")
     finally:
         wam.tune("reset")
     assert all(np.array_equal(a, b) for a, b in zip(y0, y1))
-    assert maxerr(y1, O.deharsh(x, sr)) <= TOL
+    yo = O.deharsh(x, sr)
+    assert maxerr(y1, yo) <= TOL
+    # bit-equal to the oracle on the full-level stretches (frames that mix full-level and 1e-20-scaled samples carry the
+    # transform's rounding noise of the loud part into the quiet one: any two FFTs differ there)
+    for lo, hi in ((0, sr), (4 * sr, n)):
+        d = np.concatenate([np.abs(a[lo:hi].astype(np.float64) - b[lo:hi]) for a, b in zip(y1, yo)])
+        assert (d == 0).mean() >= 0.999, (lo, (d == 0).mean())
 
 
 @pytest.mark.parametrize("sr,n,nch", [(44100, 50001, 2), (96000, 70003, 2), (48000, 30000, 1), (48000, 2047, 2), (48000, 2048 + 512, 1)])

@@ -215,7 +215,7 @@ int wam_tune(const char* key, int64_t value) {
   if (k == "dh_seg_frames" && (value == 0 || value >= 4)) t.dh_seg_frames = value;
   else if (k == "dh_warm_frames" && value >= 3) t.dh_warm_frames = value;
   else if (k == "dh_exact") t.dh_exact = value;
-  else if (k == "dh_scan_sums") t.dh_scan_sums = value;
+  else if (k == "dh_mag_bytes" && value >= 0) t.dh_mag_bytes = value;
   else if (k == "env_seg_tiles") t.env_seg_tiles = value;
   else if (k == "sc_warm_tiles" && value >= 1) t.sc_warm_tiles = value;
   else if (k == "lim_warm_tiles" && value >= 1) t.lim_warm_tiles = value;

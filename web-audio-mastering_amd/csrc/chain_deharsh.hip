@@ -638,177 +638,89 @@ __device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_
   }
 }
 // magnitude of a bin as the reference stores it: Float32Array of sqrt(re^2 + im^2) of the double spectrum (:456-460)
-__device__ __forceinline__ float mag_f32(dcx X) { return f32r(sqrt_fast(X.x * X.x + X.y * X.y)); }
-
-// ---- the reference's sequential f32 band sums without the 512-step dependent chain -----------------------------------------
-// bandEnergies[b] += mag * mag on a Float32Array (dynamic-processor.js:327-332) is s <- RN24(RN53(s + a)) bin after bin.  While the
-// running sum stays inside one binade [2^E, 2^(E+1)) it is a multiple of u = 2^(E-23), so the step is s <- s + u rint(a / u):
-// an exact, order-free add of a quantised addend (unless a / u sits on a rounding tie, where s's parity and the double
-// rounding decide: those frames take the serial walk).  Only the steps on which the sum changes binade ("crossings", ~10 per
-// band: the sum grows from the first bin's energy to the band's) need the value of s itself.  So, with lane l holding bins
-// 16 l .. 16 l + 15:
-//   1. guess every step's binade from an unrounded single-precision prefix sum per band (segmented wavefront scan);
-//   2. quantise the addends of the non-crossing steps to their guessed u and prefix-sum them per run between crossings
-//      (second segmented scan, exact in double);
-//   3. compact the crossings (addend, run sum before it) into an LDS list; lanes 0..6 walk their band's list serially
-//      with the exact step s <- f32((s + run) + a) and leave s after every crossing in the list;
-//   4. every bin rebuilds its s = s(last crossing) + run and checks its binade against the guess: if all 1024 agree, the
-//      guessed trajectory IS the true one and, by induction over the bins, every s is the sequential value.  Otherwise
-//      (a sum within ~1e-6 of a power of two, a tie, silence, denormals: a few frames in a thousand) the wavefront falls
-//      back to the serial walk.
-constexpr int kCross = 448;                      // crossing list capacity per frame (typically ~60)
-
-// DPP moves for the wavefront scans (no LDS round trip, unlike ds_bpermute): lanes without a source read 0, the identity of
-// the scans below.  row_shr:n = 0x110 + n; row_bcast:15 = 0x142 (lane 15 of every row to the next row, row mask 0xA);
-// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xC); wave_shr:1 = 0x138.
-template <int CTRL, int RM> __device__ __forceinline__ int dppm(int v) { return dpp_i<CTRL, RM>(0, v); }
-template <int CTRL, int RM> __device__ __forceinline__ float dppm(float v) { return __int_as_float(dppm<CTRL, RM>(__float_as_int(v))); }
-template <int CTRL, int RM> __device__ __forceinline__ double dppm(double v) {
-  return __hiloint2double(dppm<CTRL, RM>(__double2hiint(v)), dppm<CTRL, RM>(__double2loint(v)));
-}
-template <int CTRL, int RM, class T> __device__ __forceinline__ void seg_step(T& v, int& fl) {
-  const T pv = dppm<CTRL, RM>(v);
-  const int pf = dppm<CTRL, RM>(fl);
-  if (!fl) v += pv;
-  fl |= pf;
-}
-// start masks: bit i = bin 16 lane + i starts a segment.  Inclusive segmented prefix sum of val[16] over the wavefront.
-template <class T>
-__device__ __forceinline__ void seg_scan16(T val[16], unsigned starts, int lane) {
-  T run = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { run = ((starts >> i) & 1) ? val[i] : run + val[i]; val[i] = run; }
-  T v = run;
-  int fl = starts != 0;
-  seg_step<0x111, 0xF>(v, fl); seg_step<0x112, 0xF>(v, fl); seg_step<0x114, 0xF>(v, fl); seg_step<0x118, 0xF>(v, fl);
-  seg_step<0x142, 0xA>(v, fl); seg_step<0x143, 0xC>(v, fl);
-  const T carry = dppm<0x138, 0xF>(v);                             // wave_shr:1, lane 0 reads 0
-  const int first = starts ? __builtin_ctz(starts) : 16;
-#pragma unroll
-  for (int i = 0; i < 16; i++) if (i < first) val[i] += carry;
+// One Goldschmidt step on v_rsq_f64's 2^-24 seed leaves 1.5 seed^2 ~ 4e-15 relative: what the rounding to f32 needs (a value
+// within that of a rounding boundary, odds 6e-8 per magnitude, may land on the other side - far rarer than the transform's own
+// rounding noise does that on the weak bins); sqrt_fast's two correction steps are for the last bit of the double.
+__device__ __forceinline__ float mag_f32(dcx X) {
+  const double x = fmax(X.x * X.x + X.y * X.y, 1e-300);          // sqrt(1e-300) rounds to 0.0f: no select for silence
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g = x * y, h = 0.5 * y;
+  return f32r(fma(g, fma(-h, g, 0.5), g));
 }
 
-struct BandLanePlan { unsigned bsm, bem; uint64_t bands16; };   // band starts / ends among the lane's 16 bins, 3-bit band ids
-__device__ __forceinline__ BandLanePlan make_band_lane_plan(const DeharshPlan& P, int lane) {
-  BandLanePlan L{ 0u, 0u, 0ull };
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int k = 16 * lane + i;
-    const int b = P.band_of[k];
-    L.bands16 |= (uint64_t)b << (3 * i);
-    if (k == 0 || P.band_of[k - 1] != b) L.bsm |= 1u << i;
-    if (k == kBins - 1 || P.band_of[k + 1] != b) L.bem |= 1u << i;
-  }
-  return L;
-}
+// ---- the reference's sequential f32 band sums ------------------------------------------------------------------------------
+// bandEnergies[b] += mag * mag on a Float32Array (dynamic-processor.js:327-332) is s <- RN24(RN53(s + a)) bin after bin: a 512-step
+// dependent chain in the widest band that no reordering reproduces.  What is parallel is the FRAMES: k_dh_bands_x leaves the f32
+// magnitudes of every frame in a scratch array (4 KB per frame), and k_dh_bandsum walks them with one LANE per frame - sixty-four
+// independent chains per wavefront, the band boundaries uniform across the lanes - after transposing [64 frames][32 bins] blocks
+// through LDS so that both the loads and the walk are contiguous.  The walk is three dependent instructions per bin and is bound
+// by reading the scratch array once (8 B per sample-channel written and read on top of the stage's own traffic).
+constexpr int kSumCols = 32, kSumStride = kSumCols + 4;          // floats per LDS row: 16-byte aligned rows
 
-// LDS of one wavefront behind the 1,024 f32 magnitudes: the crossing list (addend, run before it as a count of u and the
-// biased f32 exponent that defines u; then s after the crossing) and the band results.  Slots past kCross are per-lane
-// dummies, so that the per-bin stores need no branches.
-struct BandScanLds {
-  double la[kCross + 64];
-  double lS[kCross];
-  int2 lre[kCross + 64];
-  double bandE[8 + 64];
-  int lstart[8];
-};
-__device__ __forceinline__ double run_value(int r, int e) { return ldexp((double)r, e - 150); }   // r u, u = 2^(e - 127 - 23)
-
-// Returns true if the fast path verified; then W.bandE[b] (a double holding an f32 value) is the energy of every non-empty band.
-__device__ __forceinline__ bool band_energies_scan(const float* mags, BandScanLds& W, const DeharshPlan& P, const BandLanePlan& L, int lane) {
-  float m[16];
+__global__ __launch_bounds__(256) void k_dh_bandsum(const float* __restrict__ mags, const DeharshPlan* __restrict__ dp, float* __restrict__ band_rms) {
+  __shared__ float tile[4][64 * kSumStride];
+  const DeharshPlan& P = *dp;
+  const int lane = lane_id(), wave = wave_id();
+  const int64_t F = P.nframes, chan = blockIdx.y;
+  const int64_t fb = ((int64_t)blockIdx.x * 4 + wave) * 64;      // this wavefront's 64 frames
+  if (fb >= F) return;                                           // (no workgroup barrier in this kernel)
+  const int64_t f = fb + lane;
+  const float* src = mags + chan * F * kBins;
+  float* rms_out = band_rms + (chan * F + (f < F ? f : F - 1)) * kBands;
+  float* t = tile[wave];
+  const int lr = lane >> 3, lc = lane & 7;                       // loader role: rows lr + 8 r, 16-byte column lc
+  const float* lsrc[8];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const float4 t = ((const float4*)(mags + 16 * lane))[i]; m[4 * i] = t.x; m[4 * i + 1] = t.y; m[4 * i + 2] = t.z; m[4 * i + 3] = t.w; }
-  double a[16];
-  float D[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { a[i] = (double)m[i] * (double)m[i]; D[i] = m[i] * m[i]; }
-  seg_scan16(D, L.bsm, lane);                                     // 1. the guess
-  int e[16];
-  bool bad = false;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { e[i] = (int)(__float_as_uint(D[i]) >> 23) & 0xff; bad |= e[i] < 24 || e[i] > 250; }
-  int eprev = dppm<0x138, 0xF>(e[15]);                            // the lane below's last bin (lane 0: a band start anyway)
-  unsigned xm = L.bsm;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { if (e[i] != eprev) xm |= 1u << i; eprev = e[i]; }
-  int r[16];                                                      // 2. quantised addends as counts of u (< 2^24 on a true trajectory)
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const double t = ldexp(a[i], 150 - e[i]);                    // a / u
-    const double rd = rint(t);
-    const bool cross = (xm >> i) & 1;
-    // within 2^-20 of a rounding tie (s's parity and the reference's double rounding, zone 2^-29, decide there), or absurdly large
-    if (!cross && (fabs(t - rd) > 0.49999904632568359375 || !(t < 33554432.0))) bad = true;
-    r[i] = cross ? 0 : (int)rd;
-  }
-  asm volatile("" : "+v"(xm));                                    // per-bin conditions are re-derived per phase, not kept in SGPR pairs
-  seg_scan16(r, xm, lane);                                        // wraps mod 2^32 only on a false trajectory, whose first bad bin is still exact
-  asm volatile("" : "+v"(xm));
-  int base = 0, total = 0;                                        // crossings in lower lanes / in the frame: one ballot per bin slot
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const uint64_t bal = __ballot((xm >> i) & 1);
-    base = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, base));
-    total += __builtin_popcountll(bal);
-  }
-  if (total > kCross) return false;                               // uniform
-  if (lane < 8) W.lstart[lane] = total;
-  wave_sync();
-  {                                                               // 3. the crossing list
-    int rp = dppm<0x138, 0xF>(r[15]), ep = dppm<0x138, 0xF>(e[15]), pc = base;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const bool cross = (xm >> i) & 1;
-      const int idx = cross ? pc : kCross + lane;
-      W.la[idx] = a[i];
-      W.lre[idx] = make_int2(rp, ep);
-      pc += cross;
-      rp = r[i]; ep = e[i];
+  for (int r = 0; r < 8; r++) { int64_t fr = fb + lr + 8 * r; if (fr >= F) fr = F - 1; lsrc[r] = src + fr * kBins + 4 * lc; }
+  // (eight named registers, not an array: carried around the block loop an array lands in scratch memory)
+#define WAM_SUM_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define WAM_SUM_LOAD(r) float4 nx##r = *(const float4*)lsrc[r];
+  WAM_SUM_ROWS(WAM_SUM_LOAD)
+  auto emit = [&](int b, double s) {                             // RMS per band, a Float32Array store (:335-339)
+    const float cnt = P.cnt[b];
+    const float rms = cnt > 0 ? f32r(sqrt(s / (double)cnt)) : (float)s;
+    if (f < F) rms_out[b] = rms;
+  };
+  int b = 0;
+  while (b < kBands && P.band_start[b + 1] == 0) { emit(b, 0.0); b++; }
+  int kend = b < kBands ? P.band_start[b + 1] : kBins + 1;       // bands are ascending bin ranges (make_deharsh_plan)
+  double s = 0.0;
+  auto step = [&](float mf, int knext) {                         // knext = this bin's index + 1
+    const double md = mf;
+    s = (double)f32r(fma(md, md, s));                            // m * m is exact in double: fma = RN53(s + m * m)
+    if (knext == kend) {                                         // uniform: the band ends here
+      emit(b, s);
+      s = 0.0; b++;
+      while (b < kBands && P.band_start[b + 1] == kend) { emit(b, 0.0); b++; }         // empty bands
+      kend = b < kBands ? P.band_start[b + 1] : kBins + 1;
     }
-#pragma unroll 1
-    for (int b = 0; b < kBands; b++) {                            // where every non-empty band's list starts
-      const int k0 = P.band_start[b];
-      if (k0 < P.band_start[b + 1] && lane == (k0 >> 4)) W.lstart[b] = base + __builtin_popcount(xm & ((1u << (k0 & 15)) - 1u));
+  };
+  for (int kb = 0; kb < kBins; kb += kSumCols) {
+    wave_sync();                                                 // the previous block's rows have been read
+#define WAM_SUM_PUT(r) *(float4*)(t + (lr + 8 * r) * kSumStride + 4 * lc) = nx##r;
+    WAM_SUM_ROWS(WAM_SUM_PUT)
+    wave_sync();
+    const int kn = kb + kSumCols < kBins ? kb + kSumCols : kb;    // the next block in flight during the walk (the last one re-reads itself)
+#define WAM_SUM_NEXT(r) nx##r = *(const float4*)(lsrc[r] + kn);
+    WAM_SUM_ROWS(WAM_SUM_NEXT)
+#pragma unroll
+    for (int q = 0; q < kSumCols / 4; q++) {
+      const float4 v = *(const float4*)(t + lane * kSumStride + 4 * q);
+      step(v.x, kb + 4 * q + 1); step(v.y, kb + 4 * q + 2); step(v.z, kb + 4 * q + 3); step(v.w, kb + 4 * q + 4);
     }
   }
-  wave_sync();
-  if (lane < kBands) {                                            // lane b walks band b's crossings, in order, with the exact step
-    const int ls = W.lstart[lane];
-    int le = total;
-    for (int b = lane + 1; b < 8; b++) { const int t = W.lstart[b]; if (t < le) le = t; }
-    double sv = 0.0;
-    for (int j = ls; j < le; j++) {
-      const double aj = W.la[j];
-      const int2 re = W.lre[j];
-      sv = (j == ls) ? (double)f32r(aj) : (double)f32r((sv + run_value(re.x, re.y)) + aj);
-      W.lS[j] = sv;
-    }
-  }
-  wave_sync();
-  asm volatile("" : "+v"(xm));
-  {                                                               // 4. every bin's s against the guessed binade
-    int pc = base - 1;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      pc += (xm >> i) & 1;                                        // the latest crossing at or before this bin
-      const double sk = W.lS[pc] + run_value(r[i], e[i]);
-      const int ek = (int)(__float_as_uint((float)sk) >> 23) & 0xff;
-      bad |= ek != e[i];
-      W.bandE[((L.bem >> i) & 1) ? (int)(L.bands16 >> (3 * i)) & 7 : 8 + lane] = sk;
-    }
-  }
-  wave_sync();
-  return __ballot(bad) == 0;
+#undef WAM_SUM_ROWS
+#undef WAM_SUM_LOAD
+#undef WAM_SUM_PUT
+#undef WAM_SUM_NEXT
 }
 
 __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
-                                                       float* __restrict__ band_rms, double pre_gain, int scan_sums, int win_sym) {
+                                                       float* __restrict__ mags_out, double pre_gain, int win_sym) {
   __shared__ dcx buf[4][kWaveBuf];
   __shared__ dcx tws[kTwsLds];
   __shared__ float2 winh[kM / 2];
-  static_assert(sizeof(float) * kBins + sizeof(BandScanLds) <= sizeof(dcx) * kWaveBuf, "band-sum lists fit the wavefront buffer");
   load_tables_lds(tws, winh, twd, wing);
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
@@ -816,7 +728,6 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   const int lane = lane_id(), wave = wave_id();
   dcx* z = buf[wave];
   const int ob = wave_out_base_d();
-  const BandLanePlan L = make_band_lane_plan(P, lane);
   const int64_t ngroups = (P.nframes + 3) / 4;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t f = 4 * g + wave;
@@ -834,44 +745,20 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 16; j++) z[wave_out_index_d(ob, j)] = v[j];
     wave_sync();
-    float mk[8], mm[8];
+    float* mg = mags_out + (chan * P.nframes + f) * kBins;         // magnitudes[bin], a Float32Array (:456-460): 256-byte runs per store
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
       if (k == 0) {
         const dcx z0 = z[0], zh = z[512];
-        mk[j] = f32r(fabs(z0.x + z0.y)); mm[j] = mag_f32(zh);          // X[0] = Re + Im of Z[0] (real); bin 512 = conj Z[512]
+        mg[0] = f32r(fabs(z0.x + z0.y)); mg[512] = mag_f32(zh);        // X[0] = Re + Im of Z[0] (real); bin 512 = conj Z[512]
       } else {
         const BinPairD p = split_pair_d(z[k], z[kM - k], twB[k]);
-        mk[j] = mag_f32(dcx{ p.xe.x + p.t.x, p.xe.y + p.t.y });
-        mm[j] = mag_f32(dcx{ p.xe.x - p.t.x, p.xe.y - p.t.y });
+        mg[k] = mag_f32(dcx{ p.xe.x + p.t.x, p.xe.y + p.t.y });
+        mg[kM - k] = mag_f32(dcx{ p.xe.x - p.t.x, p.xe.y - p.t.y });
       }
     }
-    wave_sync();                                                   // everybody has read Z: the buffer becomes the magnitude array
-    float* mags = (float*)z;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const int k = lane + 64 * j; mags[k] = mk[j]; mags[k == 0 ? 512 : kM - k] = mm[j]; }
-    wave_sync();
-    BandScanLds& W = *(BandScanLds*)(mags + kBins);                // the rest of the wavefront's buffer: crossing list, band results
-    BandLanePlan Lf = L;                                           // opaque per frame: the 48 per-bin conditions derived from the masks are
-    asm volatile("" : "+v"(Lf.bsm), "+v"(Lf.bem), "+v"(Lf.bands16));   // loop-invariant, and hoisted they live in ~100 SGPRs across the transform
-    const bool fast = scan_sums && band_energies_scan(mags, W, P, Lf, lane);
-    if (lane < kBands) {                                           // bandEnergies[b] += mag * mag in bin order, a Float32Array (:327-339)
-      float be = 0.0f;
-      const int k1 = fast ? 0 : P.band_start[lane + 1];              // the serial walk when the scan did not verify
-      if (fast && P.cnt[lane] > 0) be = (float)W.bandE[lane];
-      int k = P.band_start[lane];
-      for (; k + 8 <= k1; k += 8) {                                // loads up front: the adds are the dependent chain
-        float m8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) m8[u] = mags[k + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const double m = m8[u]; be = f32r((double)be + m * m); }
-      }
-      for (; k < k1; k++) { const double m = mags[k]; be = f32r((double)be + m * m); }
-      const float rms = P.cnt[lane] > 0 ? f32r(sqrt((double)be / (double)P.cnt[lane])) : be;
-      band_rms[(chan * P.nframes + f) * kBands + lane] = rms;
-    }
+    wave_sync();                                                   // everybody has read Z before the next frame's exchange
   }
 }
 
@@ -1111,10 +998,22 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   if (dp.nframes > 0) {
     const int64_t ngroups = (dp.nframes + 3) / 4;
     int64_t gx = ngroups < 2048 ? ngroups : 2048;
-    // the exact kernel's per-workgroup set-up (band plan of every lane) wants long-lived workgroups: ~8 k in all (512 are resident)
-    int64_t gxx = 8192 / nchan; if (gxx < 1) gxx = 1; if (gxx > ngroups) gxx = ngroups;
-    if (exact) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gxx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
-                          winb.as<float>(), rms.as<float>(), pre_gain, (int)(tuning().dh_scan_sums != 0), win_sym);
+    if (exact) {
+      // the magnitudes wait in scratch between the two kernels: 4 KB per frame, so a large batch goes through in groups of channels
+      const int64_t cap = tuning().dh_mag_bytes > 0 ? tuning().dh_mag_bytes : (int64_t)4 << 30;
+      int64_t sub = cap / ((int64_t)sizeof(float) * kBins * dp.nframes); if (sub < 1) sub = 1; if (sub > nchan) sub = nchan;
+      DevBuf mags;
+      rc = mags.alloc(sizeof(float) * kBins * (size_t)dp.nframes * (size_t)sub); if (rc) return rc;
+      for (int64_t c0 = 0; c0 < nchan; c0 += sub) {
+        const int64_t nc = nchan - c0 < sub ? nchan - c0 : sub;
+        int64_t gxx = 8192 / nc; if (gxx < 1) gxx = 1; if (gxx > ngroups) gxx = ngroups;
+        WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gxx, (unsigned)nc), dim3(256), s, in + c0 * n, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
+                   winb.as<float>(), mags.as<float>(), pre_gain, win_sym);
+        WAM_LAUNCH("k_dh_bandsum", k_dh_bandsum, dim3((unsigned)((dp.nframes + 255) / 256), (unsigned)nc), dim3(256), s, (const float*)mags.as<float>(),
+                   plan.as<DeharshPlan>(), rms.as<float>() + c0 * dp.nframes * kBands);
+      }
+      WAM_HIP(hipStreamSynchronize(s));            // mags is released here
+    }
     else WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),

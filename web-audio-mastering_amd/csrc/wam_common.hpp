@@ -79,7 +79,7 @@ struct Tuning {
   int64_t dh_seg_frames = 0;      // de-harsh synthesis: frames per workgroup segment, 0 = pick_segment_tiles() over frames
   int64_t dh_exact = 1;           // 1 = de-harsh kernels that reproduce every Float32Array store of the reference (double FFT, sequential
                                   // band sums); 0 = the float32 kernels (1.9x faster, ~1e-7 on the stage's own output, see chain_deharsh.hip)
-  int64_t dh_scan_sums = 1;       // exact de-harsh: band sums by segmented scans + crossing walk (0 = always the serial walk; same results)
+  int64_t dh_mag_bytes = 0;       // exact de-harsh: scratch for the frames' magnitudes between k_dh_bands_x and k_dh_bandsum (0 = 4 GiB); channels go through in groups that fit
   int64_t dh_warm_frames = 48;    // frames re-run before a segment to rebuild the resonance EMA (0.7^48 = 4e-8) and the overlap-add ring
   int64_t env_seg_tiles = 0;      // soft-clip / limiter envelopes: tiles (4096 samples) per segment, 0 = pick_segment_tiles()
   int64_t sc_warm_tiles = 3;      // soft-clip release: exp(-12288/480) = 8e-12
