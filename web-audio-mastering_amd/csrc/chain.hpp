@@ -51,8 +51,8 @@ struct Progress {
 int enqueue_front(const float* in, float* out, int ntracks, int nch, int64_t n, const FrontPlan* plan_dev, int do_glue,
                   const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double pre_gain, double sr, hipStream_t s);
 
-int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
-                      const double* gains_dev, double sr, hipStream_t s);
+int enqueue_soft_clip(const float* in, float* out, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, const double* gains_dev, double sr,
+                      hipStream_t s);
 // prog (optional): the worker limiter's own progress messages, dsp-worker.js:302,364,427,448
 int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntracks, int nch, int64_t n, const LimiterPlan* plan_dev, int L,
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s,

@@ -288,7 +288,7 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     if (do_limit) {
       rc = prog(0.85, "Applying soft clipper..."); if (rc) return rc;
       float* dst = next_dst();
-      rc = enqueue_soft_clip(src, dst, genv.as<float>(), T, nch, n, cp_d, cp.L, have_gain ? gains_d : nullptr, sr, stream); if (rc) return rc;
+      rc = enqueue_soft_clip(src, dst, T, nch, n, cp_d, have_gain ? gains_d : nullptr, sr, stream); if (rc) return rc;
       src = dst;
       rc = prog(0.95, "Applying final limiter..."); if (rc) return rc;
       dst = next_dst();
@@ -371,9 +371,8 @@ int wam_soft_clip(const float* const* ch, int nch, int64_t n, double sr, double 
   ClipPlan cp; rc = make_clip_plan(sr, ceiling_db, lookahead_ms, release_ms, drive, &cp); if (rc) return rc;
   rc = ensure_device(); if (rc) return rc;
   Staged st; rc = st.up(ch, nch, n, nullptr); if (rc) return rc;
-  DevBuf plan, genv; rc = upload_plan(cp, plan, nullptr); if (rc) return rc;
-  rc = genv.alloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
-  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), genv.as<float>(), 1, nch, n, plan.as<ClipPlan>(), cp.L, nullptr, sr, nullptr);
+  DevBuf plan; rc = upload_plan(cp, plan, nullptr); if (rc) return rc;
+  rc = enqueue_soft_clip(st.in.as<float>(), st.out.as<float>(), 1, nch, n, plan.as<ClipPlan>(), nullptr, sr, nullptr);
   if (rc) return rc;
   return st.down(st.out.as<float>(), out, nullptr);
 }

@@ -31,161 +31,173 @@ __device__ __forceinline__ double block_excl_sum(double v, double& total, double
 }
 
 // ============================================================================ soft clipper
-// Envelope.  grid = (segments, tracks).  g_out: [ntracks][n] float.
+// One kernel, grid = (segments, tracks): gain envelope, release smoothing and the oversampled saturation of a tile while its
+// samples are in registers (the envelope never goes to memory: 8 B per sample-channel read and written, nothing else).
 // A sample over the threshold (an "event") pulls the gain of the L samples before it down along a ramp
-// (soft-clipper.js:194-219): every event scatters its ramp into an LDS window of the gains of
-// [tile_base - L, tile_end) with ds_min on the float bit patterns (all values are positive, and
-// f32(min(old, new)) == min(old, f32(new))), so the cost follows the number of events, not L x samples.
-// The release pass (:222-231) is the only state that outlives the window: its memory is exp(-k/(10 ms)), so a
-// segment re-runs `warm` tiles before its first tile instead of waiting for its predecessor.
+// (soft-clipper.js:194-219): every event scatters its ramp into an LDS window of the tile's gains with ds_min on the float
+// bit patterns (all values are positive, and f32(min(old, new)) == min(old, f32(new))), so the cost follows the number of
+// events, not L x samples.  The window is [tile_base, tile_end + 2): the interpolation of a tile's last sample needs the
+// gained signal two samples on (:243-268), and a gain is final once every event up to L samples after it has been seen, so
+// each tile also looks through the next tile's first L + 2 samples for events (they scatter again, in full, as that tile's
+// own: events are ~1e-4 of the samples of a hot master).
+// The release pass (:222-231) is the only state that outlives a tile: its memory is exp(-k/(10 ms)), so a segment re-runs
+// `warm` >= 1 tiles before its first tile instead of waiting for its predecessor.
 template <int NCH>
-__global__ __launch_bounds__(kThreads) void k_sc_env(const float* __restrict__ in, int64_t n, const ClipPlan* __restrict__ cp,
-                                                     const double* __restrict__ gains, float* __restrict__ g_out,
-                                                     int64_t seg_tiles, int64_t warm) {
-  constexpr int kMaxL = kClipMaxL;
-  __shared__ unsigned gwin[kMaxL + kTile];       // gain bits of [tile_base - L, tile_end)
+__global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, float* __restrict__ out, int64_t n, const ClipPlan* __restrict__ cp,
+                                                 const double* __restrict__ gains, int64_t seg_tiles, int64_t warm) {
+  constexpr int kMaxL = kClipMaxL, kWin = kTile + 2;
+  __shared__ unsigned gwin[kWin + 2];            // gain bits of [tile_base, tile_end + 2)
   __shared__ double rt[kMaxL + 1];               // ramp position m / L  (soft-clipper.js:213-214 with i - start == L)
   __shared__ double lds_scan[kSlotDoubles];
+  __shared__ float gx[3][kThreads + 1];          // smoothed gain of every chunk's samples 0, 1, C - 1 (+ the tile's two-sample halo)
+  __shared__ float xx[NCH][3][kThreads + 1];     // the same of the gained input
+  __shared__ float carry[1 + NCH];               // the previous tile's last gain / inputs
   const ClipPlan& P = *cp;
   const int L = P.L;
   const int64_t trk = blockIdx.y;
   const double G = gains ? gains[trk] : 1.0;
-  float* go = g_out + trk * n;
+  const double ceil_lin = P.ceil_lin;
   LdsSlots slots(lds_scan);
   double Scur = 1.0;
   const unsigned one = __float_as_uint(1.0f);
-  for (int i = threadIdx.x; i < L + kTile; i += kThreads) gwin[i] = one;
+  for (int i = threadIdx.x; i < kWin; i += kThreads) gwin[i] = one;
   for (int i = threadIdx.x; i <= L; i += kThreads) rt[i] = (double)i / (double)(L > 1 ? L : 1);
-  const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  if (threadIdx.x <= NCH) carry[threadIdx.x] = threadIdx.x == 0 ? 1.0f : 0.0f;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
   const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
   const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
   __syncthreads();
+  auto gained = [&](float x) -> float { return f32r((double)x * G); };               // stage 8's Float32Array (normalizer.js:50-72)
+  // soft-clipper.js:198-216 for the sample a = |input[i]| over the threshold: its ramp, clipped to this tile's window
+  auto scatter = [&](int64_t i, double a, int64_t tile_base) {
+    const double excess = a - P.thr_lin;
+    const double normalized = excess / P.range_div;
+    const double sat = tanh_fast(normalized * P.drive);
+    const double target = P.thr_lin + sat * P.range;
+    const double red1 = target / a - 1.0;
+    if (i >= L) {
+      const int64_t j0 = i - L - tile_base;              // window index of the ramp's first sample (m = 0)
+      int m_lo = j0 < 0 ? (int)-j0 : 0, m_hi = (int64_t)kWin - 1 - j0 < L ? (int)(kWin - 1 - j0) : L;
+      for (int m = m_lo; m <= m_hi; m++) atomicMin(&gwin[j0 + m], __float_as_uint(f32r(1.0 + red1 * rt[m])));
+    } else {                                              // ramp clipped at the start of the track: start = 0 (tile 0 only)
+      const double den = (double)(i > 1 ? i : 1);
+      for (int64_t j = 0; j <= i; j++) atomicMin(&gwin[j], __float_as_uint(f32r(1.0 + red1 * ((double)j / den))));
+    }
+  };
   for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
     // pass 1: which (channel, sample) pairs are over the threshold - one compare per sample, no arithmetic behind it
+    float v[NCH][C];
     unsigned ev = 0;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      float v[C];
-      load_chunk(in + (trk * NCH + c) * n, n, base, v);
+      load_chunk(in + (trk * NCH + c) * n, n, base, v[c]);
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const double a = fabs((double)f32r((double)v[k] * G));
-        if (a > P.thr_lin && base + k < n) ev |= 1u << (c * C + k);
+        v[c][k] = gained(v[c][k]);
+        if (fabs((double)v[c][k]) > P.thr_lin && base + k < n) ev |= 1u << (c * C + k);
       }
     }
-    // pass 2 (rare: ~1e-4 of the samples of a hot master): one rolled loop over the set bits, the sample re-read from L2
+    // pass 2 (rare): one rolled loop over the set bits
     while (ev) {
       const int bit = __ffs((int)ev) - 1;
       ev &= ev - 1;
       const int c = bit / C, k = bit % C;
-      const int64_t i = base + k;
-      const double a = fabs((double)f32r((double)in[(trk * NCH + c) * n + i] * G));
-      // soft-clipper.js:200-207
-      const double excess = a - P.thr_lin;
-      const double normalized = excess / P.range_div;
-      const double sat = tanh_fast(normalized * P.drive);
-      const double target = P.thr_lin + sat * P.range;
-      const double red1 = target / a - 1.0;
-      const int wp = threadIdx.x * C + k;            // window index of sample i - L
-      if (i >= L) {
-        for (int m = 0; m <= L; m++) atomicMin(&gwin[wp + m], __float_as_uint(f32r(1.0 + red1 * rt[m])));
-      } else {                                        // ramp clipped at the start of the track: start = 0
-        const double den = (double)(i > 1 ? i : 1);
-        for (int64_t j = 0; j <= i; j++) atomicMin(&gwin[L + (int)(j - tile_base)], __float_as_uint(f32r(1.0 + red1 * ((double)j / den))));
+      scatter(base + k, fabs((double)gained(in[(trk * NCH + c) * n + base + k])), tile_base);
+    }
+    // the events of the next tile's first L + 2 samples reach back into this window
+    for (int q = threadIdx.x; q < L + 2; q += kThreads) {
+      const int64_t i = tile_base + kTile + q;
+      if (i >= n) break;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const double a = fabs((double)gained(in[(trk * NCH + c) * n + i]));
+        if (a > P.thr_lin) scatter(i, a, tile_base);
       }
     }
     __syncthreads();
-    // finalised samples of this tile: [tile_base - L, tile_end - L)
-    const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
     float gs[C], g[C];
 #pragma unroll
-    for (int k = 0; k < C; k++) { const float gv = __uint_as_float(gwin[threadIdx.x * C + k]); gs[k] = (kb + k >= 0 && kb + k < n) ? gv : 1.0f; }
-    // release smoothing (soft-clipper.js:222-231) in time order across tiles; samples before 0 are pure releases from 1.0
+    for (int k = 0; k < C; k++) { const float gv = __uint_as_float(gwin[threadIdx.x * C + k]); gs[k] = base + k < n ? gv : 1.0f; }
+    // release smoothing (soft-clipper.js:222-231) in time order across tiles
     double cur = release_solve(gs, P.rc, P.rcC, Scur, slots.next());
 #pragma unroll
     for (int k = 0; k < C; k++) { cur = release_step(cur, (double)gs[k], P.rc); g[k] = f32r(cur); }
-    if (t >= T0 && kb + C > 0) {
-      if (kb >= 0) store_chunk(go, n, kb, g);
-      else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
-    }
-    __syncthreads();
-    // slide the window by one tile: [kTile, kTile + L) -> [0, L) (disjoint, L <= kTile), then the rest back to 1.0
-    for (int i = threadIdx.x; i < L; i += kThreads) gwin[i] = gwin[kTile + i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = one;
-    __syncthreads();
-  }
-}
-
-// Apply.  One workgroup per (track, channel), grid-stride over tiles is not needed: elementwise with halo.
-__global__ __launch_bounds__(kThreads) void k_sc_apply(const float* __restrict__ in, float* __restrict__ out, int nch, int64_t n,
-                                                       const ClipPlan* __restrict__ cp, const double* __restrict__ gains,
-                                                       const float* __restrict__ genv) {
-  const ClipPlan& P = *cp;
-  const int64_t trk = blockIdx.y;                       // a block takes all channels of its chunk: the shared envelope is read once
-  const double G = gains ? gains[trk] : 1.0;
-  const float* g = genv + trk * n;
-  const double ceil_lin = P.ceil_lin;
-  for (int64_t base = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * C; base < n; base += (int64_t)gridDim.x * kThreads * C) {
-    float gv[C + 3];                   // envelope of samples base-1 .. base+C+1
-    {
-      float w[C];
-      load_chunk(g, n, base, w);
+    const bool emit = t >= T0;
+    if (emit) {
+      gx[0][threadIdx.x] = g[0]; gx[1][threadIdx.x] = g[1]; gx[2][threadIdx.x] = g[C - 1];
 #pragma unroll
-      for (int k = 0; k < C; k++) gv[k + 1] = w[k];
-      gv[0] = base - 1 >= 0 ? g[base - 1] : 1.0f;
-      gv[C + 1] = base + C < n ? g[base + C] : 1.0f;
-      gv[C + 2] = base + C + 1 < n ? g[base + C + 1] : 1.0f;
-    }
-    for (int c = 0; c < nch; c++) {
-      const float* x = in + (trk * nch + c) * n;
-      float* y = out + (trk * nch + c) * n;
-      float xv[C + 3];
-      {
-        float v[C];
-        load_chunk(x, n, base, v);
-#pragma unroll
-        for (int k = 0; k < C; k++) xv[k + 1] = v[k];
-        xv[0] = base - 1 >= 0 ? x[base - 1] : 0.0f;
-        xv[C + 1] = base + C < n ? x[base + C] : 0.0f;
-        xv[C + 2] = base + C + 1 < n ? x[base + C + 1] : 0.0f;
-      }
-      double s[C + 3];
-#pragma unroll
-      for (int k = 0; k < C + 3; k++) {
-        const int64_t i = base - 1 + k;
-        double xi = (double)f32r((double)xv[k] * G);
-        double gi = gv[k];
-        if (i < 0 || i >= n) { xi = 0; gi = 1; }
-        if (!(xi == xi)) xi = 0;                      // input[k] || 0 for NaN (neighbours only; see below)
-        if (gi == 0 || !(gi == gi)) gi = 1;           // gainEnvelope[k] || 1
-        s[k] = xi * gi;
-      }
-      float o[C];
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        // centre sample uses input[i] * gainEnvelope[i] without the || fallbacks (soft-clipper.js:242,249)
-        const double p2 = (double)f32r((double)xv[k + 1] * G), g2 = gv[k + 1];
-        double sA = p2 * g2;
-        double sB = catmull_half(s[k], p2 * g2, s[k + 2], s[k + 3]);
-        double v2[2] = { sA, sB };
+      for (int c = 0; c < NCH; c++) { xx[c][0][threadIdx.x] = v[c][0]; xx[c][1][threadIdx.x] = v[c][1]; xx[c][2][threadIdx.x] = v[c][C - 1]; }
+      if (threadIdx.x == kThreads - 1) {                  // the halo: two more steps of the recursion (not carried), two more inputs
+        const int64_t e = tile_base + kTile;
+        double h = cur;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-          const double a = fabs(v2[q]);
-          if (a > ceil_lin) {
-            const double ex = (a - ceil_lin) / ceil_lin;
-            const double red = 1 - tanh_fast(ex * 2) * 0.1;
-            const double m = fmin(a * red, ceil_lin);
-            v2[q] = v2[q] > 0 ? m : -m;
-          }
+          h = release_step(h, e + q < n ? (double)__uint_as_float(gwin[kTile + q]) : 1.0, P.rc);
+          gx[q][kThreads] = f32r(h);
+#pragma unroll
+          for (int c = 0; c < NCH; c++) xx[c][q][kThreads] = e + q < n ? gained(in[(trk * NCH + c) * n + e + q]) : 0.0f;
         }
-        o[k] = f32r((v2[0] + v2[1]) * 0.5);
       }
-      store_chunk(y, n, base, o);
     }
+    __syncthreads();
+    if (emit) {
+      // gain and 2x Catmull-Rom oversampled saturation (:234-286) of this thread's chunk; s = gained input x envelope at base-1 .. base+C+1
+      float gv[C + 3];
+#pragma unroll
+      for (int k = 0; k < C; k++) gv[k + 1] = g[k];
+      gv[0] = threadIdx.x ? gx[2][threadIdx.x - 1] : carry[0];
+      gv[C + 1] = gx[0][threadIdx.x + 1]; gv[C + 2] = gx[1][threadIdx.x + 1];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        float xv[C + 3];
+#pragma unroll
+        for (int k = 0; k < C; k++) xv[k + 1] = v[c][k];
+        xv[0] = threadIdx.x ? xx[c][2][threadIdx.x - 1] : carry[1 + c];
+        xv[C + 1] = xx[c][0][threadIdx.x + 1]; xv[C + 2] = xx[c][1][threadIdx.x + 1];
+        double s[C + 3];
+#pragma unroll
+        for (int k = 0; k < C + 3; k++) {
+          const int64_t i = base - 1 + k;
+          double xi = xv[k], gi = gv[k];
+          if (i < 0 || i >= n) { xi = 0; gi = 1; }
+          if (!(xi == xi)) xi = 0;                      // input[k] || 0 for NaN (neighbours only; see below)
+          if (gi == 0 || !(gi == gi)) gi = 1;           // gainEnvelope[k] || 1
+          s[k] = xi * gi;
+        }
+        float o[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          // centre sample uses input[i] * gainEnvelope[i] without the || fallbacks (soft-clipper.js:242,249)
+          const double sA = (double)xv[k + 1] * (double)gv[k + 1];
+          const double sB = catmull_half(s[k], sA, s[k + 2], s[k + 3]);
+          double v2[2] = { sA, sB };
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const double a = fabs(v2[q]);
+            if (a > ceil_lin) {
+              const double ex = (a - ceil_lin) / ceil_lin;
+              const double red = 1 - tanh_fast(ex * 2) * 0.1;
+              const double m = fmin(a * red, ceil_lin);
+              v2[q] = v2[q] > 0 ? m : -m;
+            }
+          }
+          o[k] = f32r((v2[0] + v2[1]) * 0.5);
+        }
+        store_chunk(out + (trk * NCH + c) * n, n, base, o);
+        __builtin_amdgcn_sched_barrier(0);                // one channel at a time: interleaved, the two take ~240 registers
+      }
+    }
+    __syncthreads();                                      // the window and the exchange arrays have been read
+    if (threadIdx.x == kThreads - 1) {
+      carry[0] = g[C - 1];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) carry[1 + c] = v[c][C - 1];
+    }
+    for (int i = threadIdx.x; i < kWin; i += kThreads) gwin[i] = one;
+    __syncthreads();
   }
 }
 
@@ -475,18 +487,16 @@ static int lds_opt_in(const void* kernel, size_t dynamic_bytes, size_t static_by
   return WAM_OK;
 }
 
-int enqueue_soft_clip(const float* in, float* out, float* genv, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, int L,
-                      const double* gains_dev, double sr, hipStream_t s) {
+int enqueue_soft_clip(const float* in, float* out, int ntracks, int nch, int64_t n, const ClipPlan* plan_dev, const double* gains_dev, double sr,
+                      hipStream_t s) {
   if (n <= 0) return WAM_OK;
+  if (in == out) { set_error("enqueue_soft_clip: in-place operation is not supported (a tile reads its neighbours' input)"); return WAM_ERR_INVALID; }
   const int64_t warm = scale_warm(tuning().sc_warm_tiles, sr);
-  const int64_t ntiles = (n + L + kTile - 1) / kTile;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
   const int64_t seg = pick_segment_tiles(ntracks, ntiles, warm, tuning().env_seg_tiles);
   const unsigned nseg = (unsigned)((ntiles + seg - 1) / seg);
-  if (nch == 2) WAM_LAUNCH("k_sc_env", k_sc_env<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
-  else WAM_LAUNCH("k_sc_env", k_sc_env<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, n, plan_dev, gains_dev, genv, seg, warm);
-  const int64_t cap = ntracks >= 32 ? 64 : 2048 / ntracks;      // ~2,048 workgroups however few the tracks
-  int64_t bx = (n + (int64_t)kThreads * C - 1) / ((int64_t)kThreads * C); if (bx > cap) bx = cap;
-  WAM_LAUNCH("k_sc_apply", k_sc_apply, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, out, nch, n, plan_dev, gains_dev, (const float*)genv);
+  if (nch == 2) WAM_LAUNCH("k_sc", k_sc<2>, dim3(nseg, ntracks), dim3(kThreads), s, in, out, n, plan_dev, gains_dev, seg, warm);
+  else WAM_LAUNCH("k_sc", k_sc<1>, dim3(nseg, ntracks), dim3(kThreads), s, in, out, n, plan_dev, gains_dev, seg, warm);
   return WAM_OK;
 }
 
