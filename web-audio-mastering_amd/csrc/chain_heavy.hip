@@ -158,6 +158,14 @@ __device__ __forceinline__ void stash_get(const SplitState& st, float v[C]) {   
 #pragma unroll
   for (int j = 0; j < C / 4; j++) { const float4 t = st.stash[j][threadIdx.x]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
 }
+__device__ __forceinline__ void band_put(float4 (*slot)[kThreads], const float v[C]) {
+#pragma unroll
+  for (int j = 0; j < C / 4; j++) slot[j][threadIdx.x] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+__device__ __forceinline__ void band_get(float4 (*slot)[kThreads], float v[C]) {
+#pragma unroll
+  for (int j = 0; j < C / 4; j++) { const float4 t = slot[j][threadIdx.x]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+}
 __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, const Biquad& hp1, const Biquad& lp2, const Biquad& hp2) {
   if (wave_id() == 0) {
     biquad_lane_power_table(lp1, lane_id(), &st.P[0][0][0]); biquad_lane_power_table(hp1, lane_id(), &st.P[1][0][0]);
@@ -238,7 +246,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
   if (threadIdx.x < 9) Scar[threadIdx.x] = threadIdx.x < 6 ? 0.0 : 1.0;
   __shared__ double alT[6][C + 2];              // follower_al_table per band: fast [b], slow [3 + b]
   if (do_punch) for (int b = 0; b < 3; b++) { follower_al_table(hp->pf_A[b], hp->pf_R[b], alT[b]); follower_al_table(hp->ps_A[b], hp->ps_R[b], alT[3 + b]); }
-  const double Psm = onepole_lane_power(hp->p_smooth, lane_id());
+  __shared__ float4 bsum[do_punch ? 2 : 1][C / 4][do_punch ? kThreads : 1];   // transient-shaped low and mid bands (own slots per thread: no barrier)
+  __shared__ double PsmT[64];                   // the smoother's lane powers: read where they are used, not held across the tile loop
+  if (do_punch && threadIdx.x < 64) PsmT[threadIdx.x] = onepole_lane_power(hp->p_smooth, threadIdx.x);
   // bypass-envelope window of this thread's chunk start, advanced tile by tile without divisions
   // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early (LR4 filters: 2 tiles; the slow transient
   // follower's 250 ms release: 48 tiles)
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * pre_gain);
     }
-    if (do_warm) {
+    if constexpr (do_warm) {
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
       prev_ctx<2>(last, pv, ctx[0], par, t == Tw);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r(acc[k]);
     }
-    if (do_punch) {
+    if constexpr (do_punch) {
       const float last[2] = { v[C - 2], v[C - 1] };
       float pv[2];
       prev_ctx<2>(last, pv, ctx[1], par, t == Tw);
@@ -308,7 +318,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
         pv[0] = x[base - 2]; pv[1] = x[base - 1];
         if (pre_gain != 1.0) { pv[0] = f32r((double)pv[0] * pre_gain); pv[1] = f32r((double)pv[1] * pre_gain); }
       }
-      double acc[C];
+      // the bands' results wait in LDS as the f32 values they are (transient-shaped band, a Float32Array): summed left to right in
+      // double at the end (:258-263), they give what a running double sum gives, without 32 registers held across two bands
       auto transient = [&](int b, const float band[C]) {
         // processTransients, multiband-transient.js:194-263
         const double fA = P.pf_A[b], fR = P.pf_R[b], sA = P.ps_A[b], sR = P.ps_R[b], tg = P.p_tg[b] - 1, sg = P.p_sg[b] - 1;
@@ -334,17 +345,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* in, flo
         }
         double s;
         double Sgb = Scar[6 + b];
-        onepole_chunk(u, P.p_smooth, Psm, Sgb, slots.next(), s);
+        onepole_chunk(u, P.p_smooth, PsmT[lane_id()], Sgb, slots.next(), s);
         if (threadIdx.x == 0) Scar[6 + b] = Sgb;
+        float r[C];
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-          const double r = (double)f32r((double)band[k] * u[k]);
-          acc[k] = (b == 0) ? r : acc[k] + r;
-        }
+        for (int k = 0; k < C; k++) r[k] = f32r((double)band[k] * u[k]);
+        if (b < 2) { band_put(bsum[b], r); return; }
+        float r0[C], r1[C];
+        band_get(bsum[0], r0); band_get(bsum[1], r1);
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = f32r(((double)r0[k] + (double)r1[k]) + (double)r[k]);
       };
       split_chunk(v, pv[1], pv[0], sp, P.p_lp1, P.p_hp1, P.p_lp2, P.p_hp2, slots, transient);
-#pragma unroll
-      for (int k = 0; k < C; k++) v[k] = f32r(acc[k]);
     }
     if (t >= T0) store_chunk(y, n, base, v);
     win += tile_q; wpos += tile_r;

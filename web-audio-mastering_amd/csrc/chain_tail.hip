@@ -187,7 +187,6 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
           o[k] = f32r((v2[0] + v2[1]) * 0.5);
         }
         store_chunk(out + (trk * NCH + c) * n, n, base, o);
-        __builtin_amdgcn_sched_barrier(0);                // one channel at a time: interleaved, the two take ~240 registers
       }
     }
     __syncthreads();                                      // the window and the exchange arrays have been read
