@@ -773,6 +773,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   __shared__ dcx tws[kTwsLds];
   __shared__ float2 winh[kM / 2];
   __shared__ float bgs[4][8];
+  __shared__ double bls[4][8];                                     // mastering preset: 10^(band gain / 20) of the frame, in double
   load_tables_lds(tws, winh, twd, wing);
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   const int ob = wave_out_base_d();
   dcx* zw = buf[wave];
   float* bg = bgs[wave];
+  double* bl = bls[wave];
   uint64_t bands = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -823,7 +825,11 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
 
     WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
     load_frame_d(x, f * kHop, Wn, pre_gain, v);
-    if (lane < kBands) bg[lane] = band_gdb[(chan * F + f) * kBands + lane];
+    if (lane < kBands) {
+      const float gb = band_gdb[(chan * F + f) * kBands + lane];
+      bg[lane] = gb;
+      if (!GEN) bl[lane] = exp_fast((double)gb * (2.30258509299404568402 / 20));
+    }
     wave_sync();
     fft1024_wave_d<false>(v, zw, T);
 #pragma unroll
@@ -838,9 +844,19 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         const double av = av_state;
         if (av > 1e-10 && (double)mag > av * 1.5) res = f32r(fmin(1.0, (div_fast((double)mag, av) - 1.5) / 2));
       }
+      if (!GEN) {
+        // 10^((g + cut) / 20) = 10^(g / 20) e^z with z = ln10 / 20 x cut in [-0.07, 0] (cut = -3 dB x res x 0.2, :369-372): the band's
+        // factor once per frame (seven lanes), the cut's by a degree-8 Taylor sum (z^9 / 9! < 1e-16); z = 0 gives the band's factor
+        // itself.  Differs from exp((g + cut) ln10 / 20) by ~1e-16 relative, far below the f32 rounding of the store (:320,:381).
+        const double z = res > 0 ? (-3.0 * 0.2 * (2.30258509299404568402 / 20)) * (double)res : 0.0;
+        double e = 1.0 / 40320;
+        e = fma(e, z, 1.0 / 5040); e = fma(e, z, 1.0 / 720); e = fma(e, z, 1.0 / 120); e = fma(e, z, 1.0 / 24);
+        e = fma(e, z, 1.0 / 6); e = fma(e, z, 0.5); e = fma(e, z, 1.0); e = fma(e, z, 1.0);
+        return (double)f32r(bl[band] * e);
+      }
       double gdb = bg[band];
-      if (res > 0) gdb += GEN ? P.max_cut * (double)res * P.sens : -3.0 * (double)res * 0.2;        // :369-372
-      if (GEN && bin >= P.ai_lo && bin <= P.ai_hi) gdb += gdb * 0.3;                                 // :375-378
+      if (res > 0) gdb += P.max_cut * (double)res * P.sens;                                          // :369-372
+      if (bin >= P.ai_lo && bin <= P.ai_hi) gdb += gdb * 0.3;                                        // :375-378
       return (double)f32r(exp_fast(gdb * (2.30258509299404568402 / 20)));   // 10^(gdb / 20) (a division by 20 would be a full IEEE
                                                                             // sequence per bin); gains is a Float32Array (:320,:381)
     };
