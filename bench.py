@@ -69,14 +69,17 @@ KERNEL_BYTES = {
     "k_warm": 8,
     "k_punch": 8,
     "k_front": 8,
-    "k_sc_env": 6,         # read x (4), write the shared gain envelope (4 per frame = 2 per sample-channel)
-    "k_sc_apply": 10,      # read x + envelope, write y
+    "k_dh_bandsum": 8,     # reads the magnitudes k_dh_bands_x left in scratch (4 KB per 512-sample hop = 8 B per sample-channel; not stage I/O)
+    "k_sc": 8,             # read x, write y (the envelope stays on chip)
     "k_lim_tm": 6,         # read x, write transient map
     "k_lim_gain": 8,       # read x + transient map, write gain envelope
     "k_lim_apply": 10,     # read x + envelope, write y
 }
 VALU_PEAK = 256 * 4 * 64 * 2.4e9 / 4       # f64 VALU lane-instructions / s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz, one issue per 4 cycles
 GROUP = 256      # tracks per render group inside the library (csrc/chain_api.hip): one launch of a chain kernel covers a group
+# kernels that go through a group in several launches (channels that fit the de-harsh magnitude scratch): the committed PMC figures
+# are per PASS over the launch's tracks (profiles/pmc_summary.py sums their launches)
+SPLIT_KERNELS = {"k_dh_bands_x", "k_dh_bandsum"}
 
 
 class SynthOpts(C.Structure):
@@ -503,24 +506,27 @@ def main():
             # the whole step against the same peak: sum over kernels of (instructions per unit x units the kernel covered in a step)
             instr = 0.0
             missing = []
+            groups_per_step = -(-T // GROUP) if chain_like else 1
+            passes = lambda k_, cnt: groups_per_step if k_ in SPLIT_KERNELS else cnt / args.steps
             for k_, (cnt, _) in prof.items():
                 ipu = pmc_instr(k_, rows)
                 if ipu is None:
                     missing.append(k_)
                     continue
-                instr += ipu * units_per_launch * (cnt / args.steps)      # per launch x launches per step
+                instr += ipu * units_per_launch * passes(k_, cnt)         # per pass over a group x passes per step
             roofline_valu["chain"] = {"instr_per_unit": instr / (T * NCH * N), "kernel_ms_per_step": kernel_ms_per_step,
                                       "achieved": instr / (kernel_ms_per_step * 1e-3), "frac": instr / (kernel_ms_per_step * 1e-3) / VALU_PEAK,
                                       "kernels_without_counters": missing}
         traffic_step = None
         if prof:
             tb_, ok = 0.0, True
+            groups_per_step = -(-T // GROUP) if chain_like else 1
             for k_, (cnt, _) in prof.items():
                 b = pmc_traffic(k_, tracks_per_launch, rows, rtracks)
                 if b is None:
                     ok = False
                     continue
-                tb_ += b * (cnt / args.steps)                      # per launch x launches per step
+                tb_ += b * (groups_per_step if k_ in SPLIT_KERNELS else cnt / args.steps)      # per pass over a group x passes per step
             traffic_step = tb_ if ok or tb_ > 0 else None
         cfg_workload = ({"chain": f"BASELINE configs[2]: {total} tracks" + (f", {T} on rank 0" if world > 1 else ""), "single": "BASELINE configs[1]: one track",
                          "longform": "BASELINE configs[3]: one long-form track"}.get(wl, "") +

@@ -559,12 +559,6 @@ __device__ __forceinline__ float2 window_pair(const WinSrc& W, int m) {   // (wi
   const float2 t = W.h[kM - 1 - m];
   return make_float2(t.y, t.x);
 }
-__device__ __forceinline__ float2 window_pair_any(const WinSrc& W, int m) {
-  if (!W.sym) return ((const float2*)W.g)[m];
-  const bool low = m < kM / 2;
-  const float2 t = W.h[low ? m : kM - 1 - m];
-  return low ? t : make_float2(t.y, t.x);
-}
 __device__ __forceinline__ void load_tables_lds(dcx* tws, float2* winh, const dcx* __restrict__ twd, const float* __restrict__ wing) {
   for (int i = threadIdx.x; i < kTwsLds; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
   for (int i = threadIdx.x; i < kM / 2; i += 256) winh[i] = ((const float2*)wing)[i];
@@ -906,7 +900,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     for (int j = 0; j < 16; j++) {
       const int m = wave_out_index_d(ob, j);
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
-      const float2 ws = window_pair_any(Wn, m);                    // the inverse's 1 / N is an exact scaling: applied to the window
+      // m = ob + 16 (j & 3) + 256 (j >> 2) with ob + 16 (j & 3) < 256: the half of the table is known from j alone
+      const float2 ws = j < 8 ? window_pair<true>(Wn, m) : window_pair<false>(Wn, m);   // the inverse's 1 / N is an exact scaling: applied to the window
       yf[m] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
     }
     wave_sync();
