@@ -1,15 +1,19 @@
 // chain_deharsh.hip - stage 1 of the export chain: processHybridDynamic(buffer, 'mastering'),
-// web/lib/dsp/dynamic-processor.js:595-609 (preset :572-585, _processChannel :444-500,
+// web/lib/dsp/dynamic-processor.js:595-609 (presets :538-585, _processChannel :444-500,
 // _computeBinGains :319-385, ResonanceDetector :194-233, GainComputer :75-90,
 // EnvelopeFollower :33-43; STFT wrapper web/lib/dsp/fft.js:41-68; Hann utils.js:98-104).
 //
-// 2048-point STFT, hop 512, per channel:
-//   k_dh_bands : every frame in parallel -> windowed FFT -> 7 band RMS values          (parallel over frames)
-//   k_dh_follow: per (channel, band) the per-frame envelope follower + soft-knee gain  (serial over frames, tiny)
-//   k_dh_apply : one wavefront per (channel, segment of frames) walks its frames in order: FFT, per-bin resonance EMA and
-//                overlap-add ring in registers, gains, inverse FFT, synthesis window, 85/15 dry/wet mix.
-// The FFT runs in float32, one wavefront per frame, sixteen points per lane (see "the transform" below); the reference's FFT
-// is double (npm fft.js, absent: parity unpinned at that boundary).  The wet path is scaled by 0.15 * 0.375, so float32 FFT
+// 2048-point STFT, hop 512, per channel.  The default kernels ("exact mode", second half of this file) compute in double and
+// round to f32 wherever the reference stores into a Float32Array:
+//   k_dh_bands_x: every frame in parallel -> windowed FFT -> the frame's 1,024 f32 magnitudes into a scratch array
+//   k_dh_bandsum: one LANE per frame walks its magnitudes bin by bin: the reference's sequential f32 band sums -> 7 band RMS values
+//   k_dh_follow : per (channel, band) the per-frame envelope follower + soft-knee gain  (serial over frames, tiny)
+//   k_dh_apply_x: one wavefront per (channel, segment of frames) walks its frames in order: FFT, per-bin resonance EMA and
+//                 overlap-add ring in registers, gains, inverse FFT, synthesis window, dry/wet mix (<true>: presets other than
+//                 'mastering', their parameters from the plan).
+// The float32 pair k_dh_bands / k_dh_apply (first half; wam_tune("dh_exact", 0)) has the same frame structure with a float32
+// transform, one wavefront per frame, sixteen points per lane (see "the transform" below); the reference's FFT is double (npm
+// fft.js, absent: parity unpinned at that boundary).  The mastering preset's wet path is scaled by 0.15 * 0.375, so float32 FFT
 // rounding (~1e-6 relative) is ~1e-7 of full scale in the stage's output (DESIGN.md 2 for what the soft clipper makes of it
 // on hard-driven masters).
 #include "chain.hpp"
@@ -492,13 +496,12 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ i
 
 
 // =====================================================================================================================
-// Exact mode (wam_tune("dh_exact", 1)).  The kernels above keep the stage within ~1e-7 of the reference, which is one f32 ulp on
-// ~9 % of its output samples; the mastering soft clipper downstream multiplies a one-ulp difference by up to ~550 on
-// hard-driven material.  The kernels below reproduce every Float32Array store of the reference instead: the
+// Exact mode (wam_tune("dh_exact", 1), the default).  The kernels above keep the stage within ~1e-7 of the reference, which is
+// one f32 ulp on ~9 % of its output samples; the mastering soft clipper downstream multiplies a one-ulp difference by up to ~550
+// on hard-driven material.  The kernels below reproduce every Float32Array store of the reference instead: the
 // transform in double (same wavefront-per-frame structure), magnitudes rounded to f32 from the double spectrum, the band
-// energies as the reference's SEQUENTIAL f32 sums in bin order (dynamic-processor.js:327-332: one lane per band walks its
-// bins), resonance / gain arithmetic in double with f32 stores where the reference has Float32Arrays.  Slower (one
-// workgroup per CU, a 512-step dependent chain per frame); the default stays the float32 path.
+// energies as the reference's SEQUENTIAL f32 sums in bin order (dynamic-processor.js:327-332: k_dh_bandsum, one lane per
+// frame), resonance / gain arithmetic in double with f32 stores where the reference has Float32Arrays.
 struct dcx { double x, y; };
 __device__ __forceinline__ dcx dmul(dcx a, dcx b) { return dcx{ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
 __device__ __forceinline__ dcx dmulc(dcx a, dcx b) { return dcx{ a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y }; }

@@ -1,8 +1,8 @@
 // chain_tail.hip - stages 8..10 of the export chain:
 //   stage 8 gain (normalizer.js:50-72) is folded into the loads of stage 9 (pre-gain G per track)
 //   stage 9 mastering soft clipper                  soft-clipper.js:165-294
-//       k_sc_env   : lookahead gain envelope (ramp minimum over the next L samples) + release smoothing
-//       k_sc_apply : gain, 2x Catmull-Rom oversampled saturation
+//       k_sc       : lookahead gain envelope (ramp minimum over the next L samples), release smoothing, gain and the 2x
+//                    Catmull-Rom oversampled saturation, one pass
 //   stage 10 lookahead true-peak limiter             dsp-worker.js:286-452
 //       k_lim_tm   : transient map (10 ms running RMS, 1 ms / 50 ms peak follower, crest factor)
 //       k_lim_gain : true-peak driven lookahead ramps (events are serial, each ramp wave-parallel) + release
