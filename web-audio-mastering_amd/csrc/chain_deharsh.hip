@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, 
   const float2* __restrict__ twB = twg + kTw1;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_uniform();
   float2* z = buf[wave];
   float* ba = bacc[wave];
 #pragma unroll
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ i
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_uniform();
   const double dry = 1 - 0.15, wetm = 0.15;                         // preset dryWetMix 0.15, dynamic-processor.js:419-423 (doubles: 0.85f is not 0.85)
   const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
   WaveTw T; load_wave_tw(twg, T, tws);
@@ -657,7 +657,7 @@ constexpr int kSumCols = 32, kSumStride = kSumCols + 4;          // floats per L
 __global__ __launch_bounds__(256) void k_dh_bandsum(const float* __restrict__ mags, const DeharshPlan* __restrict__ dp, float* __restrict__ band_rms) {
   __shared__ float tile[4][64 * kSumStride];
   const DeharshPlan& P = *dp;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_uniform();
   const int64_t F = P.nframes, chan = blockIdx.y;
   const int64_t fb = ((int64_t)blockIdx.x * 4 + wave) * 64;      // this wavefront's 64 frames
   if (fb >= F) return;                                           // (no workgroup barrier in this kernel)
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   const DeharshPlan& P = *dp;
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_uniform();
   dcx* z = buf[wave];
   const int ob = wave_out_base_d();
   const int64_t ngroups = (P.nframes + 3) / 4;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   const int64_t chan = blockIdx.y;
   const float* x = in + chan * n;
   float* y = out + chan * n;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_uniform();
   const double wetm = GEN ? P.mix : 0.15, dry = 1 - wetm;
   const bool mixed = !GEN || wetm < 1;
   const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
                                                                             // sequence per bin); gains is a Float32Array (:320,:381)
     };
     const dcx* twB = twf + kTwl + kTwq;                            // (W2048 from LDS costs this kernel 600 spilled VGPRs: left in global memory)
-#pragma unroll 1                                                   // rolled: unrolled, the eight bodies' loads are hoisted and spill
+#pragma unroll 2                                                   // two bodies in flight (all eight: their loads are hoisted and spill)
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
       const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;

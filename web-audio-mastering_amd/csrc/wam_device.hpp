@@ -39,6 +39,10 @@ struct OnePole {           // y[n] = c y[n-1] + u[n]
 // ---- small helpers ---------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// The same number as a scalar.  Work that is handed out per WAVEFRONT (frames, segments) must be indexed with this one: derived
+// from threadIdx.x the index is a per-lane value to the compiler, and every frame position, loop bound and branch that follows
+// from it becomes 64-bit vector arithmetic, exec-mask branches and selects instead of scalar code.
+__device__ __forceinline__ int wave_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ float f32r(double v) { return (float)v; }   // the Float32Array store
 
 // Make a plan pointer opaque once per tile: the compiler then reloads plan constants through the
