@@ -607,6 +607,13 @@ __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD
     for (int k3 = 0; k3 < 4; k3++) v[i + 4 * k3] = x[k3];
   }
 }
+// W2048^(lane + 64 j) = W2048^lane x W32^j: the lane's own table entry (one load per frame, issued early) times one of eight
+// literals, instead of a table load in front of every bin pair's arithmetic (their latency sat on the critical path of the
+// pair loop).  One rounding more than the table value (~1e-16), in the noise of the transform.
+__device__ __forceinline__ dcx tw2048_lane_j(dcx wl, int j) {
+  constexpr dcx W32[8] = { { 1.00000000000000000000, -0.00000000000000000000 }, { 0.98078528040323043058, -0.19509032201612824808 }, { 0.92387953251128673848, -0.38268343236508978178 }, { 0.83146961230254523567, -0.55557023301960217765 }, { 0.70710678118654757274, -0.70710678118654746172 }, { 0.55557023301960228867, -0.83146961230254523567 }, { 0.38268343236508983729, -0.92387953251128673848 }, { 0.19509032201612833135, -0.98078528040323043058 } };
+  return j == 0 ? wl : dmul(wl, W32[j]);
+}
 // slot of this lane's j-th result of fft1024_wave_d
 __device__ __forceinline__ int wave_out_base_d() { const int lane = lane_id(); return (lane >> 2) + 64 * (lane & 3); }
 __device__ __forceinline__ int wave_out_index_d(int ob, int j) { return ob + 16 * (j & 3) + 256 * (j >> 2); }
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     int toff = 0;
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
     const WaveTwD T{ tws + toff + kTwq, tws + toff };
-    const dcx* twB = twf + kTwl + kTwq;
+    const dcx wl = twf[kTwl + kTwq + lane];                        // W2048^lane
     const WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
     load_frame_d(x, f * kHop, Wn, pre_gain, v);
     wave_sync();
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
         const dcx z0 = z[0], zh = z[512];
         mg[0] = f32r(fabs(z0.x + z0.y)); mg[512] = mag_f32(zh);        // X[0] = Re + Im of Z[0] (real); bin 512 = conj Z[512]
       } else {
-        const BinPairD p = split_pair_d(z[k], z[kM - k], twB[k]);
+        const BinPairD p = split_pair_d(z[k], z[kM - k], tw2048_lane_j(wl, j));
         mg[k] = mag_f32(dcx{ p.xe.x + p.t.x, p.xe.y + p.t.y });
         mg[kM - k] = mag_f32(dcx{ p.xe.x - p.t.x, p.xe.y - p.t.y });
       }
@@ -857,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       return (double)f32r(exp_fast(gdb * (2.30258509299404568402 / 20)));   // 10^(gdb / 20) (a division by 20 would be a full IEEE
                                                                             // sequence per bin); gains is a Float32Array (:320,:381)
     };
-    const dcx* twB = twf + kTwl + kTwq;                            // (W2048 from LDS costs this kernel 600 spilled VGPRs: left in global memory)
+    const dcx wl = twf[kTwl + kTwq + lane];                        // W2048^lane (the table itself stays in global memory: no LDS left)
 #pragma unroll 2                                                   // two bodies in flight (all eight: their loads are hoisted and spill)
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         }
       } else {
         const dcx zk = zw[k], zm = zw[kM - k];
-        const dcx wtw = twB[k];
+        const dcx wtw = tw2048_lane_j(wl, j);
         const BinPairD p = split_pair_d(zk, zm, wtw);
         const dcx xk{ p.xe.x + p.t.x, p.xe.y + p.t.y }, xmc{ p.xe.x - p.t.x, p.xe.y - p.t.y };
         const double gk = bin_gain(mag_f32(xk), avg[2 * j], bk, k);
