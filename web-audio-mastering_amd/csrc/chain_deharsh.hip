@@ -614,6 +614,14 @@ __device__ __forceinline__ dcx tw2048_lane_j(dcx wl, int j) {
   constexpr dcx W32[8] = { { 1.00000000000000000000, -0.00000000000000000000 }, { 0.98078528040323043058, -0.19509032201612824808 }, { 0.92387953251128673848, -0.38268343236508978178 }, { 0.83146961230254523567, -0.55557023301960217765 }, { 0.70710678118654757274, -0.70710678118654746172 }, { 0.55557023301960228867, -0.83146961230254523567 }, { 0.38268343236508983729, -0.92387953251128673848 }, { 0.19509032201612833135, -0.98078528040323043058 } };
   return j == 0 ? wl : dmul(wl, W32[j]);
 }
+// output[i] = input[i] * (1 - mix) + output[i] * mix on a Float32Array (dynamic-processor.js:419-423).  Where the stage changes a
+// sample by exactly ten f32 ulps the sum sits on an f32 rounding tie (0.15 x 10 = 1.5 ulps) and the last bit of each PRODUCT
+// decides: three separately rounded operations as JavaScript does them, not a fused multiply-add (one sample in a thousand otherwise).
+__device__ __forceinline__ float mix_dry_wet(float dry_in, double dry, float wet_in, double wet) {
+#pragma clang fp contract(off)
+  const double a = (double)dry_in * dry, b = (double)wet_in * wet;
+  return f32r(a + b);
+}
 // slot of this lane's j-th result of fft1024_wave_d
 __device__ __forceinline__ int wave_out_base_d() { const int lane = lane_id(); return (lane >> 2) + 64 * (lane & 3); }
 __device__ __forceinline__ int wave_out_index_d(int ob, int j) { return ob + 16 * (j & 3) + 256 * (j >> 2); }
@@ -627,9 +635,9 @@ __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
   return p;
 }
 // the windowed frame is a Float32Array in the reference (fft.js:30,44): the f32 product IS that store (exact product, one rounding)
-__device__ __forceinline__ void load_frame_d(const float* __restrict__ x, int64_t pos, const WinSrc& W, double pre_gain, dcx v[16]) {
-  float2 vf[16];
-  load_frame_raw(x, pos, vf);
+// (split from the loads: the kernels issue a frame's loads while the previous frame is still being finished - load_frame_raw -
+// and window it here when its turn comes)
+__device__ __forceinline__ void window_frame_d(const float2 vf[16], const WinSrc& W, double pre_gain, dcx v[16]) {
   const int lane = lane_id();
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -733,6 +741,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   dcx* z = buf[wave];
   const int ob = wave_out_base_d();
   const int64_t ngroups = (P.nframes + 3) / 4;
+  float2 vf[16];                                                   // the next frame's samples, in flight while this one is transformed
+  if (4 * (int64_t)blockIdx.x + wave < P.nframes) load_frame_raw(x, (4 * (int64_t)blockIdx.x + wave) * kHop, vf);
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t f = 4 * g + wave;
     if (f >= P.nframes) break;
@@ -743,7 +753,11 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     const WaveTwD T{ tws + toff + kTwq, tws + toff };
     const dcx wl = twf[kTwl + kTwq + lane];                        // W2048^lane
     const WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
-    load_frame_d(x, f * kHop, Wn, pre_gain, v);
+    window_frame_d(vf, Wn, pre_gain, v);
+    {
+      const int64_t fn = f + 4 * (int64_t)gridDim.x;                // this wavefront's next frame
+      if (fn < P.nframes) load_frame_raw(x, fn * kHop, vf);
+    }
     wave_sync();
     fft1024_wave_d<false>(v, z, T);
 #pragma unroll
@@ -794,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     return v;
   };
   auto mix_out = [&](int64_t s, float wet) -> float {              // :419-423
-    return mixed ? f32r((double)load_in(s) * dry + (double)wet * wetm) : wet;
+    return mixed ? mix_dry_wet(load_in(s), dry, wet, wetm) : wet;
   };
   const int64_t F = P.nframes;
   const int64_t f0 = seg * seg_frames;
@@ -828,7 +842,11 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     WaveTwD T{ tws + toff + kTwq, tws + toff };
 
     WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
-    load_frame_d(x, f * kHop, Wn, pre_gain, v);
+    {                                                              // (loads a frame ahead cost this kernel 32 registers it does not have)
+      float2 vf[16];
+      load_frame_raw(x, f * kHop, vf);
+      window_frame_d(vf, Wn, pre_gain, v);
+    }
     if (lane < kBands) {
       const float gb = band_gdb[(chan * F + f) * kBands + lane];
       bg[lane] = gb;
@@ -895,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
         }
       }
     }
-    if (!synth) continue;
+    if (!synth) continue;                                          // a warm-up frame: analysis only
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
@@ -918,18 +936,26 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     const float* yw = (const float*)zw;
     const int64_t pos = f * kHop;
     const int rot = (int)(pos & (kN - 1)), jdone = (int)(f & 3);
+    // This frame completes its first hop: ring slots 8 jdone .. 8 jdone + 7 of every lane = samples pos + lane + 64 jj.  Their dry
+    // inputs are loaded together and ahead of the ring's LDS reads (inside the per-slot branch each load sat in front of its use).
+    const bool emit = f >= f0;
+    float dryv[8];
+    if (emit && mixed) {
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-      const int i = (lane + 64 * j - rot) & (kN - 1);
-      acc[j] += yw[i];
-      if ((j >> 3) == jdone) {
-        if (f >= f0) {
-          const int64_t s = pos + i;
-          y[s] = mix_out(s, f32r((double)acc[j] / 4.0));
-        }
-        acc[j] = 0.0f;
-      }
+      for (int jj = 0; jj < 8; jj++) dryv[jj] = load_in(pos + lane + 64 * jj);
     }
+#pragma unroll
+    for (int j = 0; j < 32; j++) acc[j] += yw[(lane + 64 * j - rot) & (kN - 1)];
+#define WAM_DH_FINISH(G)                                                                              \
+    _Pragma("unroll") for (int jj = 0; jj < 8; jj++) {                                                \
+      if (emit) {                                                                                     \
+        const float wet = f32r((double)acc[8 * G + jj] / 4.0);                                        \
+        y[pos + lane + 64 * jj] = mixed ? mix_dry_wet(dryv[jj], dry, wet, wetm) : wet;               \
+      }                                                                                               \
+      acc[8 * G + jj] = 0.0f;                                                                         \
+    }
+    if (jdone == 0) { WAM_DH_FINISH(0) } else if (jdone == 1) { WAM_DH_FINISH(1) } else if (jdone == 2) { WAM_DH_FINISH(2) } else { WAM_DH_FINISH(3) }
+#undef WAM_DH_FINISH
   }
   if (!last_seg) return;
   wave_sync();
