@@ -91,6 +91,18 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
     // pass 1: which (channel, sample) pairs are over the threshold - one compare per sample, no arithmetic behind it
     float v[NCH][C];
     unsigned ev = 0;
+    // the look-ahead samples of the first L + 2 threads and the last thread's halo inputs are requested together with the chunks:
+    // loaded where they are used, each would stand between two barriers with the whole workgroup waiting on one wavefront
+    float la[NCH], hx[NCH][2];
+    const int64_t li = tile_base + kTile + threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      la[c] = (threadIdx.x < L + 2 && li < n) ? in[(trk * NCH + c) * n + li] : 0.0f;
+      if (threadIdx.x == kThreads - 1) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) hx[c][q] = tile_base + kTile + q < n ? in[(trk * NCH + c) * n + tile_base + kTile + q] : 0.0f;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       load_chunk(in + (trk * NCH + c) * n, n, base, v[c]);
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
       if (i >= n) break;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        const double a = fabs((double)gained(in[(trk * NCH + c) * n + i]));
+        const double a = fabs((double)gained(q < kThreads ? la[c] : in[(trk * NCH + c) * n + i]));
         if (a > P.thr_lin) scatter(i, a, tile_base);
       }
     }
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
           h = release_step(h, e + q < n ? (double)__uint_as_float(gwin[kTile + q]) : 1.0, P.rc);
           gx[q][kThreads] = f32r(h);
 #pragma unroll
-          for (int c = 0; c < NCH; c++) xx[c][q][kThreads] = e + q < n ? gained(in[(trk * NCH + c) * n + e + q]) : 0.0f;
+          for (int c = 0; c < NCH; c++) xx[c][q][kThreads] = gained(hx[c][q]);
         }
       }
     }
