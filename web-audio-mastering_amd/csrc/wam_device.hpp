@@ -29,7 +29,12 @@ constexpr int kTile = kThreads * C;    // 4096 samples
 // ---- host-prepared plans ---------------------------------------------------
 struct Biquad {            // y[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2] - a1 y[n-1] - a2 y[n-2]
   double b0, b1, b2, a1, a2;
-  double Mp[7][4];         // M^(2^k), k = 0..6, M = transition of the state over one chunk (C samples)
+  // The scans run on the state in MODAL coordinates u = T (y[-1], y[-2]), T = [[1, -tc], [0, td]] (plan_tables.cpp): with the
+  // pole pair rho e^{+-i theta}, tc = rho cos(theta), td = rho sin(theta), the chunk transition becomes a rotation-scaling of
+  // norm <= 1 and its powers, products and weighted sums lose nothing - in the companion basis a 30 Hz section has
+  // |M^k| ~ 250 with cancellation everywhere, and the start states were off by 1e-9.  tid = 1 / td.  Real poles: T = identity.
+  double tc, td, tid;
+  double Mp[7][4];         // (T M T^-1)^(2^k), k = 0..6, M = transition of the state over one chunk (C samples)
 };
 struct OnePole {           // y[n] = c y[n-1] + u[n]
   double c;
@@ -276,9 +281,9 @@ __device__ __forceinline__ void biquad_pre(double x[C], double xm1, double xm2, 
     const double y = w - a1 * p1 - a2 * p2;
     p2 = p1; p1 = y;
   }
-  double e0 = p1, e1 = p2;
+  double e0 = fma(-q.tc, p2, p1), e1 = q.td * p2;    // the chunk's zero-state end state in modal coordinates (struct Biquad)
   const int lane = lane_id();
-  m.S0 = Slds[0]; m.S1 = Slds[1];                    // read before the caller's barrier; rewritten after it
+  m.S0 = Slds[0]; m.S1 = Slds[1];                    // (modal too) read before the caller's barrier; rewritten after it
   // weighted prefix sum of the end states: inside the rows of 16 lanes by DPP row shifts (uniform powers M^1, M^2, M^4, M^8) ...
 #define WAM_SCAN2_ROW(K, CTRL) { const double t0 = dpp_d<CTRL, 0xF>(0.0, e0), t1 = dpp_d<CTRL, 0xF>(0.0, e1); \
     e0 += q.Mp[K][0] * t0 + q.Mp[K][1] * t1; e1 += q.Mp[K][2] * t0 + q.Mp[K][3] * t1; }
@@ -313,8 +318,10 @@ __device__ __forceinline__ void biquad_post(double x[C], const Biquad& q, const 
   }
   if (threadIdx.x == 0) { Slds[0] = w0; Slds[1] = w1; }
   const double* P = Plds + lane;
-  s0 = m.x0 + P[0] * my0 + P[64] * my1;
-  s1 = m.x1 + P[128] * my0 + P[192] * my1;
+  const double u0 = m.x0 + P[0] * my0 + P[64] * my1;
+  const double u1 = m.x1 + P[128] * my0 + P[192] * my1;
+  s1 = u1 * q.tid;                                   // back to (y[-1], y[-2])
+  s0 = fma(q.tc, s1, u0);
   double p1 = s0, p2 = s1;
 #pragma unroll
   for (int n = 0; n < C; n++) {

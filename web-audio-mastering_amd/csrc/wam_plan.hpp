@@ -13,18 +13,13 @@ inline void mat2_mul_h(const double a[4], const double b[4], double o[4]) {
   std::memcpy(o, t, sizeof(t));
 }
 
-// Fill the scan tables of a biquad from its five coefficients.
+// Fill the scan tables of a biquad from its five coefficients: the modal transform and the powers of the chunk transition in
+// modal coordinates, evaluated in quadruple precision on the host (plan_tables.cpp says why).
+extern "C" void wam_biquad_scan_tables(double a1, double a2, int chunk, double Mp[7][4], double T3[3]);
 inline void finish_biquad(Biquad& q) {
-  // homogeneous responses
-  double h1[C], h2[C];
-  double p1 = 1, p2 = 0;
-  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; h1[n] = y; p2 = p1; p1 = y; }
-  p1 = 0; p2 = 1;
-  for (int n = 0; n < C; n++) { const double y = -q.a1 * p1 - q.a2 * p2; h2[n] = y; p2 = p1; p1 = y; }
-  // state after C samples: (y[C-1], y[C-2]) = M (y[-1], y[-2])
-  q.Mp[0][0] = h1[C - 1]; q.Mp[0][1] = h2[C - 1];
-  q.Mp[0][2] = h1[C - 2]; q.Mp[0][3] = h2[C - 2];
-  for (int k = 1; k < 7; k++) mat2_mul_h(q.Mp[k - 1], q.Mp[k - 1], q.Mp[k]);
+  double T3[3];
+  wam_biquad_scan_tables(q.a1, q.a2, C, q.Mp, T3);
+  q.tc = T3[0]; q.td = T3[1]; q.tid = T3[2];
 }
 inline Biquad make_biquad(double b0, double b1, double b2, double a1, double a2) {
   Biquad q; q.b0 = b0; q.b1 = b1; q.b2 = b2; q.a1 = a1; q.a2 = a2; finish_biquad(q); return q;
