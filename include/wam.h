@@ -79,6 +79,12 @@ const char* wam_last_error(void);
 int wam_init(int device);
 int wam_device_count(int* count);
 const char* wam_version(void);
+/* Version of THIS header's signatures.  Bumped whenever an existing entry point changes its parameter list (2: wam_normalize
+ * and wam_limiter gained (wam_progress_cb, void*); 3: round 3, no signature changed, entry points added): a binding compares
+ * wam_abi_version() with the WAM_ABI_VERSION it was written against before its first call and refuses to run on a mismatch,
+ * instead of passing a stale argument list.  The in-tree bindings (napi/wam_napi.cc, python/wam.py) do. */
+#define WAM_ABI_VERSION 3
+int wam_abi_version(void);
 
 /* ---- metering ----------------------------------------------------------- */
 /* measureLUFS(audioBuffer, fallbackLufs), web/lib/dsp/lufs.js:17-82 (worker twin
@@ -167,14 +173,17 @@ int wam_batch_meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, do
                         double fallback, double* lufs, double* dbtp, void* stream);
 
 /* wam_batch_meter_dev for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code that runs under
- * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels and numbers as wam_batch_meter_dev,
- * but: (1) what that entry point takes from the library's workspace pool (plan, per-hop sums, peaks, block energies, gate
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels as wam_batch_meter_dev; LUFS / dBTP agree with
+ * it to ~1e-12 (the closing log10 runs on the device here, on the host there).  Differences: (1) what that entry point takes from the library's workspace pool (plan, per-hop sums, peaks, block energies, gate
  * results) lives in a fixed 64 MiB device array that every GPU holds from the moment it loads the library until the process
  * ends; (2) the results go to the CALLER's device arrays lufs_dev / dbtp_dev [ntracks] (either may be NULL), so there is
  * no device-to-host copy and no synchronisation: the call only enqueues on `stream`; (3) it calls no hipMalloc / hipFree or
  * other allocating routine - call wam_init(device) once beforehand, which looks the array's address up on that device.
  * A batch whose scratch does not fit (1,024 three-minute stereo tracks need 44.5 MB) is refused with WAM_ERR_TOO_LARGE.
- * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two host threads, two streams) race. */
+ * All calls on one GPU share that GPU's array, so they are ordered on the device: each call's stream first waits (no host
+ * synchronisation) for an event recorded behind the previous call's last kernel on that GPU - calls from two streams or two
+ * host threads run one after the other.  Under stream capture the event is not used: two graphs that contain this call must
+ * not run at the same time on one GPU. */
 int wam_batch_meter_dev_noalloc(const float* in_dev, int ntracks, int nch, int64_t n, double sample_rate,
                                 double fallback, double* lufs_dev, double* dbtp_dev, void* stream);
 

@@ -147,6 +147,65 @@ async function gpu() {
     const ab = new wam.WamAudioBuffer({ numberOfChannels: 1, length: c.n, sampleRate: c.sr }); ab.copyToChannel(f32(c.input[0]), 0);
     const w1 = wam.encodeWAV(ab, c.sr, 16, { ditherSeed: 7 }), w2 = wam.encodeWAV(ab, c.sr, 16, { ditherSeed: 7 }), w3 = wam.encodeWAV(ab, c.sr, 16, { ditherSource: 'math-random' });
     ok(Buffer.compare(Buffer.from(w1), Buffer.from(w2)) === 0 && w3.length === w1.length, 'pcm16 seeded dither is reproducible'); }
+  // The reference's own hot-path tests (web/ui/encoder.test.js:35-92), restated against the shim with a duck-typed buffer that,
+  // like the reference's fixture (:4-12), has numberOfChannels, sampleRate and getChannelData - and NO `length` field.
+  { const duck = (channels, sampleRate = 48000) => ({ numberOfChannels: channels.length, sampleRate, getChannelData(i) { return channels[i]; } });
+    const header = (wav) => { const v = new DataView(wav.buffer, wav.byteOffset, wav.byteLength); return { sampleRate: v.getUint32(24, true), bitDepth: v.getUint16(34, true), dataSize: v.getUint32(40, true) }; };
+    const pcm16 = (wav) => { const v = new DataView(wav.buffer, wav.byteOffset, wav.byteLength); const o = new Int16Array((wav.byteLength - 44) / 2); for (let i = 0; i < o.length; i++) o[i] = v.getInt16(44 + 2 * i, true); return o; };
+    // :36-44 target sample rate and bit depth in the header, from a 48 k buffer
+    { const wav = await wam.encodeWAVAsync(duck([new Float32Array([0, 0.25, -0.25, 0.5])], 48000), 44100, 16, { ditherMode: 'none' });
+      const h = header(wav);
+      ok(h.sampleRate === 44100 && h.bitDepth === 16 && h.dataSize === 8, `encoder.test: header ${JSON.stringify(h)}`);
+      const q = pcm16(wav); ok(q[0] === 0 && q[1] === Math.round(0.25 * 32767) && q[2] === Math.round(-0.25 * 32767) && q[3] === Math.round(0.5 * 32767), `encoder.test: 16-bit none samples ${Array.from(q)}`); }
+    // :46-54 shouldCancel
+    { let msg = ''; try { await wam.encodeWAVAsync(duck([new Float32Array(32768)], 48000), 48000, 16, { shouldCancel: () => true }); } catch (e) { msg = e.message; }
+      ok(msg === 'Cancelled', `encoder.test: shouldCancel rejects with 'Cancelled', got '${msg}'`); }
+    // :56-65 16-bit 'none' is deterministic
+    { const src = new Float32Array(512); src.fill(0.00123); const a = wam.encodeWAV(duck([src]), 48000, 16, { ditherMode: 'none' }), b = wam.encodeWAV(duck([src]), 48000, 16, { ditherMode: 'none' });
+      ok(a.length === 44 + 1024 && Buffer.compare(Buffer.from(a), Buffer.from(b)) === 0, 'encoder.test: none is deterministic'); }
+    // :67-80 TPDF differs from none - with the device generator, and with the reference's own Math.random draws on a length-less buffer
+    { const src = new Float32Array(4096); src.fill(0.00001);
+      const none = pcm16(wam.encodeWAV(duck([src]), 48000, 16, { ditherMode: 'none' }));
+      for (const opt of [{ ditherMode: 'tpdf' }, { ditherMode: 'tpdf', ditherSource: 'math-random' }]) {
+        const t = pcm16(wam.encodeWAV(duck([src]), 48000, 16, opt));
+        ok(t.length === none.length && none.some((v, i) => v !== t[i]), `encoder.test: tpdf differs from none (${opt.ditherSource || 'device'})`);
+        ok(t.every((v) => v >= -1 && v <= 2), 'encoder.test: tpdf stays within one LSB of the input level');
+      } }
+    // :82-91 24-bit ignores the dither mode
+    { const src = new Float32Array(1024); src.fill(0.03125);
+      const a = wam.encodeWAV(duck([src]), 48000, 24, { ditherMode: 'none' }), b = wam.encodeWAV(duck([src]), 48000, 24, { ditherMode: 'noise-shaped' });
+      ok(a.length === 44 + 3072 && Buffer.compare(Buffer.from(a), Buffer.from(b)) === 0, 'encoder.test: 24-bit ignores dither mode'); }
+    // encodeWAVAsync's chunk loop (encoder.js:189-243): cancel polled before every chunk, progress end / numSamples after every chunk,
+    // a yield between chunks, a closing 1, chunkSize floor of 1024; the bytes equal encodeWAV's
+    { const n = 5000; const src = new Float32Array(n); for (let i = 0; i < n; i++) src[i] = Math.sin(i * 0.01) * 0.7;
+      const prog = []; let polls = 0, yields = 0; const t0 = setInterval(() => {}, 1000);
+      const tick = () => { yields++; };
+      const pr = wam.encodeWAVAsync(duck([src, src]), 48000, 24, { chunkSize: 100, onProgress: (p) => { prog.push(p); setTimeout(tick, 0); }, shouldCancel: () => { polls++; return false; } });
+      const wav = await pr; clearInterval(t0);
+      const want = [1024 / n, 2048 / n, 3072 / n, 4096 / n, 1, 1];
+      ok(prog.length === want.length && prog.every((v, i) => v === want[i]), `encodeWAVAsync progress ${prog}`);
+      ok(polls === 5, `encodeWAVAsync polls shouldCancel before every chunk (${polls})`);
+      ok(yields >= 4, `encodeWAVAsync yields between chunks (${yields} timers ran before it resolved)`);
+      ok(Buffer.compare(Buffer.from(wav), Buffer.from(wam.encodeWAV(duck([src, src]), 48000, 24))) === 0, 'encodeWAVAsync bytes equal encodeWAV');
+      let seen = 0, msg = '';
+      try { await wam.encodeWAVAsync(duck([src]), 48000, 16, { chunkSize: 1024, shouldCancel: () => ++seen === 3, onProgress: () => {} }); } catch (e) { msg = e.message; }
+      ok(msg === 'Cancelled' && seen === 3, `encodeWAVAsync cancels at the third chunk (${seen}, '${msg}')`);
+      const empty = await wam.encodeWAVAsync(duck([new Float32Array(0)]), 48000, 16, {});
+      ok(empty.length === 44 && header(empty).dataSize === 0, 'encodeWAVAsync of an empty buffer is a header'); } }
+  // submit-time snapshot (worker-interface.js:116-132 slices every channel before posting): a caller that edits its buffer while the
+  // request waits in the queue must not change the result
+  { const c = golden['chain_core_1s']; const ab = track(c), ab2 = track(c);
+    const first = w.renderFullChain(ab, c.settings, c.mode);           // occupies the queue
+    const second = w.renderFullChain(ab2, c.settings, c.mode);         // waits behind it
+    ab2.getChannelData(0).fill(0); ab2.getChannelData(1).fill(0);      // edited after submission
+    const [r1, r2] = await Promise.all([first, second]);
+    ok(maxAbsDiff(r2.audioBuffer.getChannelData(0), r1.audioBuffer.getChannelData(0)) === 0 && maxAbsDiff(r2.audioBuffer.getChannelData(1), r1.audioBuffer.getChannelData(1)) === 0,
+       'a queued request renders the buffer as it was when it was submitted');
+    const wk = new wam.WamWorker(); const ch = [track(c).getChannelData(0), track(c).getChannelData(1)];
+    const reply = await new Promise((resolve) => { wk.onmessage = (e) => { if (e.data.type !== 'PROGRESS') resolve(e.data); };
+      wk.postMessage({ type: 'RENDER_FULL_CHAIN', id: 1, data: { channels: ch, sampleRate: c.sr, settings: c.settings, mode: c.mode } }); ch[0].fill(0); ch[1].fill(0); });
+    ok(reply.success && maxAbsDiff(reply.result.channels[0], r1.audioBuffer.getChannelData(0)) === 0, 'WamWorker.postMessage snapshots the channels when the message is posted');
+    wk.terminate(); }
   // the Worker-shaped adapter: the reference's message protocol (dsp-worker.js:1-9)
   { const c = golden['chain_core_1s']; const ab = track(c);
     const wk = new wam.WamWorker();

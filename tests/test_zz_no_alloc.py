@@ -62,6 +62,36 @@ def test_noalloc_meter_matches_batch_meter_twice():
     assert np.all(np.isneginf(l)) and np.all(np.isneginf(p))                       # silence
 
 
+def test_noalloc_calls_on_two_streams_do_not_race():
+    """Two calls back to back on two non-blocking streams, no host synchronisation between them: both carve the same per-GPU
+    scratch array, so the second must wait on the device for the first (the per-device event of noalloc.hip).  Without that
+    order the second call's plan and cleared hop sums overwrite the first's while its k_meter / k_gate are running."""
+    wam.init(0)
+    sr = 48000
+    a = synth(96, 2, 48000 * 20, sr, 700, quiet=(200000, 500000, 0.002))           # ~10 ms of kernels: still running when the next call is enqueued
+    b = synth(5, 2, 70001, sr, 800)
+    want = [wam.batch_meter_dev(x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], sr) for x in (a, b)]
+    for rep in range(3):
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        torch.cuda.synchronize()
+        for x, st in ((a, s1), (b, s2), (a, s2), (b, s1)):
+            T, nch, n = x.shape
+            lufs = torch.full((T,), float("nan"), dtype=torch.float64, device="cuda")
+            dbtp = torch.full((T,), float("nan"), dtype=torch.float64, device="cuda")
+            outs.append((lufs, dbtp))
+        torch.cuda.synchronize()
+        for (x, st), (lufs, dbtp) in zip(((a, s1), (b, s2), (a, s2), (b, s1)), outs):
+            T, nch, n = x.shape
+            wam._check(wam.lib().wam_batch_meter_dev_noalloc(C.c_void_p(x.data_ptr()), C.c_int(T), C.c_int(nch), C.c_int64(n), C.c_double(sr), C.c_double(-14.0),
+                                                             C.c_void_p(lufs.data_ptr()), C.c_void_p(dbtp.data_ptr()), C.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize()
+        for k, (lufs, dbtp) in enumerate(outs):
+            wl, wp = want[k & 1]
+            assert np.max(np.abs(lufs.cpu().numpy() - wl)) <= 1e-9, (rep, k)
+            assert np.max(np.abs(dbtp.cpu().numpy() - wp)) <= 1e-9, (rep, k)
+
+
 def test_noalloc_meter_rejects_what_does_not_fit():
     wam.init(0)
     x = torch.zeros((1, 1, 16), dtype=torch.float32, device="cuda")

@@ -9,6 +9,10 @@ bench.synth_dev(xd, 1, 3, {"amp": 1.6, "clickAmp": 0.6})          # the library'
 x = [xd[0, 0].cpu().numpy(), xd[0, 1].cpu().numpy()]
 s = dict(wam.DEFAULT_SETTINGS, glueCompression=True, eqLow=1, eqLowMid=-2, eqMid=1, eqHighMid=-1, eqHigh=2)
 wam.init(0)
+import os
+pinned = int(os.environ.get("WAM_STAGE_PINNED", "1"))
+wam.tune("stage_pinned", pinned)          # 0 = hipMemcpyAsync on the caller's pageable memory (round 2), 1 = the pinned ring of staging.hip
+print(f"stage_pinned = {pinned}")
 for name, fn in (("render_full_chain", lambda: wam.render_full_chain(x, sr, s, "export")), ("meter", lambda: wam.meter(x, sr)),
                  ("encode_pcm24", lambda: wam.encode_pcm24(x))):
     fn()
@@ -29,3 +33,18 @@ t0 = time.perf_counter()
 wam.batch_render(tracks, sr, s, "export")
 dt = time.perf_counter() - t0
 print(f"batch_render: {T} tracks in {dt * 1e3:.0f} ms incl. H2D/D2H from pageable host memory = {T * 180 / dt:.0f} x realtime")
+outs = [np.zeros(n, dtype=np.float32) for _ in range(2 * T)]          # output arrays a caller reuses: their pages exist already
+t0 = time.perf_counter()
+wam.batch_render(tracks, sr, s, "export", outs=outs)
+dt = time.perf_counter() - t0
+print(f"batch_render into reused output arrays: {T} tracks in {dt * 1e3:.0f} ms = {T * 180 / dt:.0f} x realtime")
+
+if os.environ.get("WAM_HOST_SWEEP"):
+    for hg in (8, 16, 32, 64):
+        for th in (2, 4):
+            wam.tune("host_group", hg); wam.tune("stage_threads", th)
+            wam.batch_render(tracks[:hg], sr, s, "export")
+            t0 = time.perf_counter()
+            wam.batch_render(tracks, sr, s, "export")
+            dt = time.perf_counter() - t0
+            print(f"host_group {hg:3d} stage_threads {th}: {dt * 1e3:.0f} ms = {T * 180 / dt:.0f} x realtime", flush=True)

@@ -41,10 +41,31 @@ static thread_local hipStream_t g_scope_stream = nullptr;
 StreamScope::StreamScope(hipStream_t s) : prev_(g_scope_stream) { g_scope_stream = s; }
 StreamScope::~StreamScope() { g_scope_stream = prev_; }
 
+// Idle events are recycled per device (a render call releases dozens of blocks: creating and destroying an event for each
+// was host overhead on the single-track latency path), and a block's event is waited for AFTER g_pool_mu has been released,
+// so one stream that is still busy does not stall every other worker's alloc and free.
+static std::vector<std::pair<int, hipEvent_t>> g_spare_events;     // (device, event); guarded by g_pool_mu
+static hipEvent_t take_event(int dev) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_spare_events.size(); i++)
+      if (g_spare_events[i].first == dev) { const hipEvent_t e = g_spare_events[i].second; g_spare_events.erase(g_spare_events.begin() + i); return e; }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+static void give_event(int dev, hipEvent_t e) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_spare_events.size() < 256) { g_spare_events.emplace_back(dev, e); return; }
+  (void)hipEventDestroy(e);
+}
+
 void* pool_alloc(size_t bytes, size_t* granted) {
   const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(2) << 20) : 256;
   const size_t want = (bytes + gran - 1) / gran * gran;
   int dev = 0; (void)hipGetDevice(&dev);
+  PoolBlock hit{nullptr, 0, 0, nullptr};
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int best = -1;
@@ -53,16 +74,18 @@ void* pool_alloc(size_t bytes, size_t* granted) {
       if (b.device != dev || b.bytes < want || b.bytes > want + want / 4 + 4096) continue;      // best fit, at most 25 % slack
       if (best < 0 || b.bytes < g_pool[best].bytes) best = i;
     }
-    if (best >= 0) {
-      const PoolBlock b = g_pool[best];
-      g_pool.erase(g_pool.begin() + best);
-      *granted = b.bytes;
-      if (b.idle) {                                     // the previous owner's last work on this block (usually long done)
-        if (hipEventQuery(b.idle) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b.idle); }
-        (void)hipEventDestroy(b.idle);
+    if (best >= 0) { hit = g_pool[best]; g_pool.erase(g_pool.begin() + best); }
+  }
+  if (hit.p) {
+    *granted = hit.bytes;
+    if (hit.idle) {                                     // the previous owner's last work on this block (usually long done)
+      if (hipEventQuery(hit.idle) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipEventSynchronize(hit.idle) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }   // (never leave a sticky error for the next launch check)
       }
-      return b.p;
+      give_event(dev, hit.idle);
     }
+    return hit.p;
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
@@ -78,8 +101,8 @@ void* pool_alloc(size_t bytes, size_t* granted) {
 void pool_free(void* p, size_t granted) {
   if (!p) return;
   int dev = 0; (void)hipGetDevice(&dev);
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, g_scope_stream) != hipSuccess) {
+  hipEvent_t ev = take_event(dev);
+  if (!ev || hipEventRecord(ev, g_scope_stream) != hipSuccess) {
     (void)hipGetLastError();
     if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     (void)hipStreamSynchronize(g_scope_stream);      // no event: make the block idle the slow way
@@ -142,9 +165,9 @@ static int check_audio(const float* const* ch, int nch, int64_t n, int max_nch =
 static int upload(const float* const* ch, int nch, int64_t n, DevBuf& buf, hipStream_t stream) {
   int rc = buf.alloc(sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1));
   if (rc) return rc;
-  for (int c = 0; c < nch && n > 0; c++)
-    WAM_HIP(hipMemcpyAsync(buf.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream));
-  return WAM_OK;
+  std::vector<HostSeg> segs;
+  for (int c = 0; c < nch && n > 0; c++) segs.push_back(HostSeg{ (void*)ch[c], buf.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n });
+  return staged_copy(segs.data(), (int)segs.size(), true, stream);
 }
 
 static int meter_dev(const float* in_dev, int ntracks, int nch, int64_t n, double sr, double fallback,
@@ -181,7 +204,8 @@ using namespace wam;
 extern "C" {
 
 const char* wam_last_error(void) { return g_err.c_str(); }
-const char* wam_version(void) { return "wam-hip 0.1 (gfx950)"; }
+const char* wam_version(void) { return "wam-hip 0.3 (gfx950)"; }
+int wam_abi_version(void) { return WAM_ABI_VERSION; }
 
 int wam_debug_counters(uint64_t out[8], int reset) {
   for (int i = 0; i < 8; i++) out[i] = 0;
@@ -197,13 +221,16 @@ int wam_debug_counters(uint64_t out[8], int reset) {
 }
 int wam_trim_workspace(void) {
   std::vector<wam::PoolBlock> blocks;
-  { std::lock_guard<std::mutex> lk(wam::g_pool_mu); blocks.swap(wam::g_pool); }
+  std::vector<std::pair<int, hipEvent_t>> spare;
+  { std::lock_guard<std::mutex> lk(wam::g_pool_mu); blocks.swap(wam::g_pool); spare.swap(wam::g_spare_events); }
   int cur = 0; (void)hipGetDevice(&cur);
   for (const auto& b : blocks) {
     (void)hipSetDevice(b.device);
     if (b.idle) { (void)hipEventSynchronize(b.idle); (void)hipEventDestroy(b.idle); }
     (void)hipFree(b.p);
   }
+  for (const auto& e : spare) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); }
+  wam::staging_trim();
   (void)hipSetDevice(cur);
   return WAM_OK;
 }
@@ -226,6 +253,9 @@ int wam_tune(const char* key, int64_t value) {
   else if (k == "meter_warm_tiles" && value >= 3) t.meter_warm_tiles = value;
   else if (k == "glue_warm_tiles" && value >= 3) t.glue_warm_tiles = value;
   else if (k == "stft_literal") t.stft_literal = value;
+  else if (k == "stage_pinned") t.stage_pinned = value;
+  else if (k == "stage_threads" && value >= 1 && value <= 8) t.stage_threads = value;
+  else if (k == "host_group" && value >= 1 && value <= 256) t.host_group = value;
   else if (k == "reset") t = wam::Tuning();
   else { wam::set_error("wam_tune: unknown key or value out of range: %s = %lld", key, (long long)value); return WAM_ERR_INVALID; }
   return WAM_OK;

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -110,15 +111,14 @@ struct Staged {            // host planar channels <-> contiguous device [nch][n
     const size_t bytes = sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1);
     int rc = in.alloc(bytes); if (rc) return rc;
     rc = out.alloc(bytes); if (rc) return rc;
-    for (int c = 0; c < nch && n > 0; c++)
-      WAM_HIP(hipMemcpyAsync(in.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
-    return WAM_OK;
+    std::vector<HostSeg> segs;
+    for (int c = 0; c < nch && n > 0; c++) segs.push_back(HostSeg{ (void*)ch[c], in.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n });
+    return staged_copy(segs.data(), (int)segs.size(), true, s);
   }
   int down(const float* src, float* const* o, hipStream_t s) {
-    for (int c = 0; c < nch && n > 0; c++)
-      WAM_HIP(hipMemcpyAsync(o[c], src + (size_t)c * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
-    WAM_HIP(hipStreamSynchronize(s));
-    return WAM_OK;
+    std::vector<HostSeg> segs;
+    for (int c = 0; c < nch && n > 0; c++) segs.push_back(HostSeg{ (void*)o[c], (void*)(src + (size_t)c * n), sizeof(float) * (size_t)n });
+    return staged_copy(segs.data(), (int)segs.size(), false, s);
   }
 };
 
@@ -462,14 +462,32 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
   return render_batch_dev(in_dev, out_dev, ntracks, nch, n, sr, settings, mode, results, (hipStream_t)stream, nullptr, nullptr);
 }
 
-// Host-pointer batch on ONE device.  Tracks go through the device in staging groups of 8; up to `max_workers` host threads, each
-// with its own stream and staging buffers, pull groups from a shared counter, so some groups' H2D / D2H copies run while other
-// groups' kernels do (copies from pageable memory are staged by the runtime and block their thread: 1 thread moves ~18 GB/s,
-// 8 threads ~35 GB/s against 221 ms of kernels per 128 tracks).  Results are independent of the split: tracks never interact.
+// Host-pointer batch on ONE device.  Tracks go through the device in staging groups of `host_group` tracks (32: a group's 64
+// channels fill the chip with little time segmentation; groups of 8 spent 261 ms in kernels per 128 tracks where one batch takes
+// 184); up to `max_workers` host threads, each with its own stream and device buffers, pull groups from a shared counter, so
+// some groups' copies run while other groups' kernels do.  The copies go through the pinned rings of staging.hip (a ring and
+// stage_threads copy threads per worker while it copies).  Results are independent of
+// the split: tracks never interact.
+// Worker streams are kept for the life of the process (per device, handed out again): an idle event of the workspace pool may
+// outlive the worker that recorded it, and the runtime looks at the recording stream when such an event is queried later - a
+// destroyed stream there surfaced as 'operation not permitted when stream is capturing' on an unrelated launch.
+static std::mutex g_wstream_mu;
+static std::vector<std::pair<int, hipStream_t>> g_wstreams;
+static hipStream_t worker_stream_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_wstream_mu);
+    for (size_t i = 0; i < g_wstreams.size(); i++) if (g_wstreams[i].first == device) { hipStream_t s = g_wstreams[i].second; g_wstreams.erase(g_wstreams.begin() + i); return s; }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return s;
+}
+static void worker_stream_release(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_wstream_mu); g_wstreams.emplace_back(device, s); }
+
 static int batch_render_host(int device, const float* const* in, int ntracks, int nch, int64_t n, double sr, const wam_settings* settings, int mode,
                              float* const* out, wam_result* results, int max_workers) {
   const size_t per = (size_t)nch * (size_t)(n > 0 ? n : 1);
-  const int group = 8;                                // tracks per staging group
+  const int group = (int)tuning().host_group;          // tracks per staging group
   const int ngroups = (ntracks + group - 1) / group;
   const int nworkers = ngroups < max_workers ? ngroups : max_workers;
   std::atomic<int> next{0};
@@ -478,8 +496,8 @@ static int batch_render_host(int device, const float* const* in, int ntracks, in
   auto worker = [&](int w) {
     auto fail = [&](int code) { rcs[w] = code; errs[w] = wam_last_error(); next.store(ngroups); };   // error strings are per thread
     if (bind_device(device) != WAM_OK) return fail(WAM_ERR_NO_DEVICE);
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(WAM_ERR_HIP); }
+    hipStream_t st = worker_stream_acquire(device);
+    if (!st) { set_error("hipStreamCreate failed"); return fail(WAM_ERR_HIP); }
     auto body = [&]() -> int {
       const StreamScope scope(st);
       DevBuf din, dout;
@@ -489,23 +507,27 @@ static int batch_render_host(int device, const float* const* in, int ntracks, in
         const int gi = next.fetch_add(1);
         if (gi >= ngroups) break;
         const int t0 = gi * group, g = ntracks - t0 < group ? ntracks - t0 : group;
+        std::vector<HostSeg> segs;
         for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
-          WAM_HIP(hipMemcpyAsync(din.as<float>() + ((size_t)t * nch + c) * n, in[(size_t)(t0 + t) * nch + c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+          segs.push_back(HostSeg{ (void*)in[(size_t)(t0 + t) * nch + c], din.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n });
+        r = staged_copy(segs.data(), (int)segs.size(), true, st); if (r) return r;
         r = render_batch_dev(din.as<float>(), dout.as<float>(), g, nch, n, sr, settings, mode, results ? results + t0 : nullptr, st, nullptr, nullptr);
         if (r) return r;
+        segs.clear();
         for (int t = 0; t < g; t++) for (int c = 0; c < nch && n > 0; c++)
-          WAM_HIP(hipMemcpyAsync(out[(size_t)(t0 + t) * nch + c], dout.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-        WAM_HIP(hipStreamSynchronize(st));
+          segs.push_back(HostSeg{ (void*)out[(size_t)(t0 + t) * nch + c], dout.as<float>() + ((size_t)t * nch + c) * n, sizeof(float) * (size_t)n });
+        r = staged_copy(segs.data(), (int)segs.size(), false, st); if (r) return r;
       }
       return WAM_OK;
     };
     const int r = body();
-    (void)hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
+    if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+    worker_stream_release(device, st);
     if (r) fail(r);
   };
+  // (a std::system_error from thread creation must not cross the C ABI: the workers that did start drain the queue)
   std::vector<std::thread> extra;
-  for (int w = 1; w < nworkers; w++) extra.emplace_back(worker, w);
+  try { for (int w = 1; w < nworkers; w++) extra.emplace_back(worker, w); } catch (...) {}
   worker(0);
   for (auto& t : extra) t.join();
   for (int w = 0; w < nworkers; w++) if (rcs[w]) { set_error("%s", errs[w].c_str()); return rcs[w]; }
@@ -523,7 +545,7 @@ int wam_batch_render(const float* const* in, int ntracks, int nch, int64_t n, do
   int rc = check_batch(in, ntracks, nch, n, sr, settings, out); if (rc) return rc;
   rc = ensure_device(); if (rc) return rc;
   int device = 0; WAM_HIP(hipGetDevice(&device));
-  return batch_render_host(device, in, ntracks, nch, n, sr, settings, mode, out, results, 8);
+  return batch_render_host(device, in, ntracks, nch, n, sr, settings, mode, out, results, 4);
 }
 
 // Multi-device batch: entry i of `devices` renders the contiguous track range
@@ -539,7 +561,7 @@ int wam_batch_render_multi(const float* const* in, int ntracks, int nch, int64_t
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error("no HIP device available (this backend has no CPU path)"); return WAM_ERR_NO_DEVICE; }
   for (int i = 0; i < ndev; i++) if (devices[i] < 0 || devices[i] >= count) { set_error("devices[%d] = %d out of range (0..%d)", i, devices[i], count - 1); return WAM_ERR_INVALID; }
   int before = -1; (void)hipGetDevice(&before);
-  const int per_dev_workers = ndev >= 4 ? 2 : 8 / ndev;                // staging threads per entry: ~8 in all
+  const int per_dev_workers = ndev >= 2 ? 2 : 4;                       // workers per entry (each drives up to stage_threads copy threads)
   std::vector<int> rcs(ndev, WAM_OK);
   std::vector<std::string> errs(ndev);
   auto entry = [&](int i) {
@@ -548,9 +570,15 @@ int wam_batch_render_multi(const float* const* in, int ntracks, int nch, int64_t
     rcs[i] = batch_render_host(devices[i], in + lo * nch, (int)(hi - lo), nch, n, sr, settings, mode, out + lo * nch, results ? results + lo : nullptr, per_dev_workers);
     if (rcs[i]) errs[i] = wam_last_error();
   };
+  // (thread creation may throw std::system_error, which must not cross the C ABI: an entry whose thread could not be
+  // started runs on the caller's thread after entry 0)
   std::vector<std::thread> threads;
-  for (int i = 1; i < ndev; i++) threads.emplace_back(entry, i);
+  std::vector<int> inline_entries;
+  for (int i = 1; i < ndev; i++) {
+    try { threads.emplace_back(entry, i); } catch (...) { inline_entries.push_back(i); }
+  }
   entry(0);
+  for (int i : inline_entries) entry(i);
   for (auto& t : threads) t.join();
   if (before >= 0) (void)bind_device(before);                           // entry 0 ran on the caller's thread: restore its device
   for (int i = 0; i < ndev; i++) if (rcs[i]) { set_error("device entry %d (device %d): %s", i, devices[i], errs[i].c_str()); return rcs[i]; }

@@ -231,8 +231,8 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   int ring = 0;                                        // stays 0 while W <= kTile
   for (int i = threadIdx.x; i < padi(W) + 8; i += kThreads) tail[i] = 0;
   __syncthreads();
-  // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact after W <= 1024 samples
-  // and the peak follower forgets as exp(-k / (50 ms))
+  // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact once W samples (10 ms; the
+  // warm-up is 25 tiles at 48 kHz and scales with the rate) have been seen, and the peak follower forgets as exp(-k / (50 ms))
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
@@ -490,10 +490,23 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------- launchers
-// A kernel whose static + dynamic LDS exceeds the 64 KB default must be opted in (gfx950 has 160 KB per workgroup).
-static int lds_opt_in(const void* kernel, size_t dynamic_bytes, size_t static_bytes) {
+// A kernel whose static + dynamic LDS exceeds the 64 KB default must be opted in, up to what the device has per workgroup
+// (gfx950: 160 KB; asked of the device once, not assumed).  A window that does not fit is the caller's sample rate being too
+// high for this device: WAM_ERR_TOO_LARGE with the rate in the message, not a raw HIP launch error.
+static int lds_opt_in(const void* kernel, size_t dynamic_bytes, size_t static_bytes, double sr, const char* what) {
   if (dynamic_bytes + static_bytes <= 64 * 1024) return WAM_OK;
-  if (dynamic_bytes + static_bytes > 160 * 1024) { set_error("window of %zu bytes does not fit the 160 KB of LDS", dynamic_bytes); return WAM_ERR_TOO_LARGE; }
+  static thread_local int cached_dev = -1;
+  static thread_local size_t cached_max = 0;
+  int dev = 0; WAM_HIP(hipGetDevice(&dev));
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 64 * 1024; }
+    cached_dev = dev; cached_max = (size_t)v;
+  }
+  if (dynamic_bytes + static_bytes > cached_max) {
+    set_error("%s: the window of %zu + %zu bytes at sample rate %.1f does not fit this device's %zu bytes of LDS per workgroup", what, dynamic_bytes, static_bytes, sr, cached_max);
+    return WAM_ERR_TOO_LARGE;
+  }
   WAM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes));
   return WAM_OK;
 }
@@ -533,7 +546,8 @@ int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntr
     const unsigned nseg = (unsigned)(((n + kTile - 1) / kTile + seg - 1) / seg);
     const int W = (int)std::floor(sr * 10 / 1000);                    // = LimiterPlan::W (dsp-worker.js:308-309)
     const size_t tail_bytes = sizeof(double) * (size_t)(W + (W >> 4) + 8);
-    int rc = lds_opt_in((const void*)(nch == 2 ? k_lim_tm<2> : k_lim_tm<1>), tail_bytes, sizeof(double) * (kTile + kTile / 16 + 8 + kSlotDoubles + 4));
+    int rc = lds_opt_in((const void*)(nch == 2 ? k_lim_tm<2> : k_lim_tm<1>), tail_bytes, sizeof(double) * (kTile + kTile / 16 + 8 + kSlotDoubles + 4) + 64, sr,
+                        "limiter transient map (10 ms RMS window)");
     if (rc) return rc;
     if (nch == 2) WAM_LAUNCH_SHMEM("k_lim_tm", k_lim_tm<2>, dim3(nseg, ntracks), dim3(kThreads), tail_bytes, s, in, n, plan_dev, tm, seg, warm);
     else WAM_LAUNCH_SHMEM("k_lim_tm", k_lim_tm<1>, dim3(nseg, ntracks), dim3(kThreads), tail_bytes, s, in, n, plan_dev, tm, seg, warm);
@@ -542,6 +556,11 @@ int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntr
   const float* tmi = preserve ? tm : nullptr;
   const unsigned nsegg = (unsigned)(((n + L + kTile - 1) / kTile + seg - 1) / seg);
   const size_t gwin_bytes = sizeof(float) * (size_t)(L + kTile);
+  {
+    int rc = lds_opt_in((const void*)(nch == 2 ? k_lim_gain<2> : k_lim_gain<1>), gwin_bytes, sizeof(double) * kSlotDoubles + sizeof(float) * 2 * kCtxFloats + 64, sr,
+                        "limiter gain envelope (3 ms look-ahead window)");
+    if (rc) return rc;
+  }
   if (nch == 2) WAM_LAUNCH_SHMEM("k_lim_gain", k_lim_gain<2>, dim3(nsegg, ntracks), dim3(kThreads), gwin_bytes, s, in, n, plan_dev, tmi, genv, seg, warm);
   else WAM_LAUNCH_SHMEM("k_lim_gain", k_lim_gain<1>, dim3(nsegg, ntracks), dim3(kThreads), gwin_bytes, s, in, n, plan_dev, tmi, genv, seg, warm);
   if ((prc = say(0.6, "Applying limiting..."))) return prc;

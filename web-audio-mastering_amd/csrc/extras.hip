@@ -377,8 +377,9 @@ static int check_in(const float* const* ch, int nch, int64_t n, int max_nch = 2)
 }
 static int upload_chans(const float* const* ch, int nch, int64_t n, DevBuf& b) {
   int rc = b.alloc(sizeof(float) * (size_t)nch * (size_t)(n > 0 ? n : 1)); if (rc) return rc;
-  for (int c = 0; c < nch && n > 0; c++) WAM_HIP(hipMemcpyAsync(b.as<float>() + (size_t)c * n, ch[c], sizeof(float) * (size_t)n, hipMemcpyHostToDevice, nullptr));
-  return WAM_OK;
+  std::vector<HostSeg> segs;
+  for (int c = 0; c < nch && n > 0; c++) segs.push_back(HostSeg{ (void*)ch[c], b.as<float>() + (size_t)c * n, sizeof(float) * (size_t)n });
+  return staged_copy(segs.data(), (int)segs.size(), true, nullptr);
 }
 
 }  // namespace wam
@@ -629,7 +630,7 @@ int wam_apply_gain(const float* const* ch, int nch, int64_t n, double gain_db, f
 
 int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out) {
   int rc = check_in(ch, nch, n); if (rc) return rc;
-  if (!out) { set_error("out is NULL"); return WAM_ERR_INVALID; }
+  if (!out && n > 0) { set_error("out is NULL"); return WAM_ERR_INVALID; }       // (an empty buffer's output has no address: a header-only file)
   rc = ensure_device(); if (rc) return rc;
   if (n == 0) return WAM_OK;
   DevBuf in, o;
@@ -646,7 +647,7 @@ int wam_encode_pcm24(const float* const* ch, int nch, int64_t n, uint8_t* out) {
 
 int wam_encode_pcm16(const float* const* ch, int nch, int64_t n, int dither_mode, const float* dither, uint32_t seed, uint8_t* out) {
   int rc = check_in(ch, nch, n); if (rc) return rc;
-  if (!out || dither_mode < 0 || dither_mode > 2) { set_error("invalid 16-bit encoder arguments (dither_mode 0..2)"); return WAM_ERR_INVALID; }
+  if ((!out && n > 0) || dither_mode < 0 || dither_mode > 2) { set_error("invalid 16-bit encoder arguments (out NULL, or dither_mode outside 0..2)"); return WAM_ERR_INVALID; }
   rc = ensure_device(); if (rc) return rc;
   if (n == 0) return WAM_OK;
   DevBuf in, o, dd;

@@ -43,6 +43,11 @@ struct StreamScope {
   hipStream_t prev_;
 };
 
+// Host <-> device copies of the host-pointer entry points through a resident pinned ring and a few copy threads (staging.hip).
+struct HostSeg { void* host; void* dev; size_t bytes; };
+int staged_copy(const HostSeg* segs, int nsegs, bool to_device, hipStream_t stream);   // synchronises `stream` before it returns
+void staging_trim();                                                                    // frees the idle pinned rings
+
 // RAII device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -91,6 +96,9 @@ struct Tuning {
   int64_t meter_warm_tiles = 4;   // a straddling 100 ms hop reaches back 1.17 tiles; K-weighting high-pass e^-20 per tile
   int64_t stft_literal = 0;       // 1 = always use the stage-by-stage STFT kernel (the register-blocked one must equal it bit for bit)
   int64_t glue_warm_tiles = 50;   // glue follower, 250 ms release (+2 for the straddling hop)
+  int64_t stage_pinned = 1;       // host-pointer entry points: 1 = copies through the pinned ring (staging.hip), 0 = hipMemcpyAsync on the caller's pageable memory
+  int64_t stage_threads = 4;      // copy threads per staged copy (1..8)
+  int64_t host_group = 32;        // wam_batch_render: tracks per staging group (each group is one device batch)
 };
 Tuning tuning();          // a snapshot (wam_tune is a test / tuning hook: a request that overlaps a wam_tune call may see either value per kernel)
 

@@ -42,6 +42,10 @@ export class WamAudioBuffer {
 }
 
 function chansOf(ab) { const r = []; for (let c = 0; c < ab.numberOfChannels; c++) r.push(ab.getChannelData(c)); return r; }
+// Copies of the channels, taken when a request is SUBMITTED: the reference slices every channel before it posts the message
+// (_extractChannelData, worker-interface.js:116-132), so what a caller does to its buffer while the request waits in the queue
+// does not reach the worker.  (The addon copies once more when the request runs; that copy is the one the device reads.)
+function snapshotOf(ab) { return chansOf(ab).map((c) => c.slice()); }
 function makeAB(channels, sampleRate) {
   const Ctor = (typeof globalThis.AudioBuffer === 'function') ? globalThis.AudioBuffer : WamAudioBuffer;
   const ab = new Ctor({ numberOfChannels: channels.length, length: channels[0].length, sampleRate });
@@ -142,7 +146,8 @@ export function removeDCOffset(channel) {                                       
 //   'math-random'       (Math.random() + Math.random()) - 1 per sample-channel on this thread, exactly the reference's draws
 //   Float32Array        caller-supplied values in LSB units, one per sample-channel, interleaved order
 export function encodeWAV(audioBuffer, targetSampleRate, bitDepth, options = {}) {
-  const n = audioBuffer.length, nch = audioBuffer.numberOfChannels;
+  // (the sample count is channel 0's length, encoder.js:63: the reference's own test buffer has no `length` field)
+  const nch = audioBuffer.numberOfChannels, n = audioBuffer.getChannelData(0).length;
   const bits = bitDepth === 24 ? 24 : 16;
   const sampleRate = targetSampleRate || audioBuffer.sampleRate;
   let pcm;
@@ -169,12 +174,27 @@ export function encodeWAV(audioBuffer, targetSampleRate, bitDepth, options = {})
   out.set(pcm, 44);
   return out;
 }
-export async function encodeWAVAsync(audioBuffer, targetSampleRate, bitDepth, options = {}) {   // encoder.js:143
-  const { onProgress = null, shouldCancel = null } = options || {};
-  if (shouldCancel && shouldCancel()) throw new Error('Cancelled');
-  const r = encodeWAV(audioBuffer, targetSampleRate, bitDepth, options);
+// encodeWAVAsync - web/ui/encoder.js:143-244.  The caller-visible contract of the reference's chunk loop is kept call for call:
+// shouldCancel() is polled before every chunk of options.chunkSize frames (default 65536, at least 1024, :189) and 'Cancelled' is
+// thrown when it says so, onProgress(end / numSamples) follows every chunk, the function yields to the event loop between chunks
+// (never after the last), and a final onProgress(1) precedes the result.  The quantiser itself is ONE device pass over the whole
+// buffer, made when the first chunk is due (the 16-bit noise shaper carries its error from frame to frame, so chunks are not
+// independent work); the loop then replays the chunk boundaries.  A cancel in mid-file discards a result that already exists.
+export async function encodeWAVAsync(audioBuffer, targetSampleRate, bitDepth, options = {}) {
+  const { onProgress = null, shouldCancel = null, chunkSize = 65536 } = options || {};
+  const numSamples = audioBuffer.getChannelData(0).length;
+  const safeChunkSize = Math.max(1024, Number(chunkSize) || 65536);
+  let wav = null;
+  for (let i = 0; i < numSamples; i += safeChunkSize) {
+    if (shouldCancel && shouldCancel()) throw new Error('Cancelled');
+    if (wav === null) wav = encodeWAV(audioBuffer, targetSampleRate, bitDepth, options || {});
+    const end = Math.min(i + safeChunkSize, numSamples);
+    if (onProgress) onProgress(end / numSamples);
+    if (end < numSamples) await new Promise((resolve) => setTimeout(resolve, 0));
+  }
+  if (wav === null) wav = encodeWAV(audioBuffer, targetSampleRate, bitDepth, options || {});      // an empty buffer: header only
   if (onProgress) onProgress(1);
-  return r;
+  return wav;
 }
 export function stftDb(audioBuffer, nfft = 4096, hop = 1024) {                       // spectrogram.js:113-143, batched
   return addon().stftDb(chansOf(audioBuffer), audioBuffer.sampleRate, nfft, hop);
@@ -203,7 +223,9 @@ export class WamWorker {
   constructor(device = 0) { addon().init(device); this.onmessage = null; this.onerror = null; this._tail = Promise.resolve(); this._dead = false; }
   _emit(data) { if (!this._dead && typeof this.onmessage === 'function') this.onmessage({ data }); }
   postMessage(msg /*, transferables */) {
-    const { type, id, data } = msg;
+    const { type, id } = msg;
+    // postMessage clones (or takes over) the message when it is posted, not when the worker gets to it: snapshot the channels now
+    const data = (msg.data && Array.isArray(msg.data.channels)) ? Object.assign({}, msg.data, { channels: msg.data.channels.map((c) => c.slice()) }) : msg.data;
     const progress = (p, status) => this._emit({ id, type: 'PROGRESS', progress: p, status });
     this._tail = this._tail.then(async () => {
       if (this._dead) return;
@@ -260,30 +282,30 @@ export class DSPWorkerInterface {
     });
   }
   async measureLUFS(audioBuffer) {                                                   // :162
-    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const ch = snapshotOf(audioBuffer), sr = audioBuffer.sampleRate;
     const r = await this._send(() => addon().meter(ch, sr, -14));
     return { lufs: r.lufs };
   }
   async findTruePeak(audioBuffer) {                                                  // :178
-    const ch = chansOf(audioBuffer);
+    const ch = snapshotOf(audioBuffer);
     const r = await this._send(() => addon().meter(ch, 48000, -14));      // rate-independent, dsp-worker.js:1361-1363
     return { peakDB: r.peakDB };
   }
   async normalize(audioBuffer, targetLUFS = -14, ceilingDB = -1, onProgress = null) {   // :197
-    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const ch = snapshotOf(audioBuffer), sr = audioBuffer.sampleRate;
     const r = await this._send(() => addon().normalize(ch, sr, targetLUFS, ceilingDB, onProgress || undefined));
     return { audioBuffer: makeAB(r.channels, sr), currentLUFS: r.currentLUFS, finalLUFS: r.finalLUFS, peakDB: r.peakDB,
       gainApplied: r.gainApplied, limiterApplied: r.limiterApplied };
   }
   async applyLimiter(audioBuffer, options = {}, onProgress = null) {                 // :227, defaults dsp-worker.js:1385-1389
-    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const ch = snapshotOf(audioBuffer), sr = audioBuffer.sampleRate;
     const p = [options.ceilingLinear || 0.891, options.lookaheadMs || 3, options.releaseMs || 100, options.kneeDB || 3,
       options.preserveTransients !== false ? 1 : 0];
     const out = await this._send(() => addon().stage('limiter', ch, sr, p, onProgress || undefined));
     return { audioBuffer: makeAB(out, sr) };
   }
   async renderFullChain(audioBuffer, settings, mode = 'preview', onProgress = null) {  // :259
-    const ch = chansOf(audioBuffer), sr = audioBuffer.sampleRate;
+    const ch = snapshotOf(audioBuffer), sr = audioBuffer.sampleRate;
     const r = await this._send(() => addon().renderChain(ch, sr, settings, mode, onProgress || undefined));
     return { audioBuffer: makeAB(r.channels, sr), lufs: r.lufs, measuredLufs: r.measuredLufs };
   }

@@ -480,6 +480,10 @@ napi_value init_dev(napi_env env, napi_callback_info info) {
 napi_value device_count(napi_env env, napi_callback_info) { int n = 0; wam_device_count(&n); napi_value v; napi_create_int32(env, n, &v); return v; }
 
 napi_value Init(napi_env env, napi_value exports) {
+  if (wam_abi_version() != WAM_ABI_VERSION) {          // a libwam_hip.so with other signatures than this addon was compiled against
+    napi_throw_error(env, nullptr, "wam: libwam_hip.so ABI version differs from the one this addon was built against (include/wam.h)");
+    return exports;
+  }
   const napi_property_descriptor props[] = {
     {"init", nullptr, init_dev, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     {"deviceCount", nullptr, device_count, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
