@@ -1,4 +1,4 @@
-"""Host logic of the biquad scans (csrc/plan_tables.cpp): the modal transform and the powers of the chunk transition, checked
+"""Host logic of the biquad scans (csrc/plan_tables.cpp): the shift of the state coordinates and the powers of the chunk transition there, checked
 against exact rational arithmetic.  The tables are what the start state of every 16-sample chunk is rebuilt from; off by 1e-9
 (repeated squaring in double, companion basis) they put 2 % of a 30 Hz high-pass's f32 stores on the other side of a rounding
 boundary than the reference's sequential loop, and the mastering soft clipper multiplies such a flip by ~600
@@ -19,10 +19,10 @@ CHUNK = 16
 
 def tables(a1, a2):
     lib = C.CDLL(SO)
-    mp = ((C.c_double * 4) * 7)()
-    t3 = (C.c_double * 3)()
-    lib.wam_biquad_scan_tables(C.c_double(a1), C.c_double(a2), C.c_int(CHUNK), mp, t3)
-    return np.array([[v for v in row] for row in mp]), list(t3)
+    mp = ((C.c_double * 3) * 7)()
+    tc = C.c_double(0)
+    lib.wam_biquad_scan_tables(C.c_double(a1), C.c_double(a2), C.c_int(CHUNK), mp, C.byref(tc))
+    return np.array([[v for v in row] for row in mp]), tc.value
 
 
 def rbj_poles(f, q, sr):          # denominator of the RBJ low / high-pass (utils.js:59-73, final-filters.js:22-43)
@@ -36,28 +36,28 @@ def mat_mul(x, y):
             [x[1][0] * y[0][0] + x[1][1] * y[1][0], x[1][0] * y[0][1] + x[1][1] * y[1][1]]]
 
 
-@pytest.mark.parametrize("f,q,sr,modal", [(30, 0.707, 48000, True), (30, 0.707, 96000, True), (80, 0.7071, 48000, True), (200, 0.707, 44100, True),
-                                          (4000, 0.707, 48000, True), (38.13547087602444, 0.5, 48000, False)])
-def test_tables_are_correctly_rounded(f, q, sr, modal):
+@pytest.mark.parametrize("f,q,sr", [(30, 0.707, 48000), (30, 0.707, 96000), (80, 0.7071, 48000), (200, 0.707, 44100), (4000, 0.707, 48000),
+                                    (38.13547087602444, 0.5, 48000), (100, 0.3, 48000)])
+def test_tables_are_correctly_rounded(f, q, sr):
+    """Pole pairs, the double pole of the K-weighting high-pass (Q = 0.5) and real poles (Q = 0.3): T A^n T^-1 with
+    T = [[1, -c], [0, 1]] in exact rational arithmetic has the form [[a, -delta b], [b, a]], and the table is its correct rounding."""
     a1, a2 = rbj_poles(f, q, sr)
-    mp, (tc, td, tid) = tables(a1, a2)
-    assert (tc != 0 or td != 1) == modal                  # Q = 0.5 is a double real pole: companion basis kept
-    assert tid == 1.0 / td
-    if modal:
-        assert tc == -a1 / 2 and abs(td - math.sqrt(a2 - tc * tc)) <= 1e-9 * td
+    mp, tc = tables(a1, a2)
+    assert tc == -a1 / 2
+    delta = F(a2) - F(tc) * F(tc)
     A = [[-F(a1), -F(a2)], [F(1), F(0)]]
     P = [[F(1), F(0)], [F(0), F(1)]]
     for _ in range(CHUNK):
         P = mat_mul(A, P)
-    T = [[F(1), -F(tc)], [F(0), F(td)]]
-    Ti = [[F(1), F(tc) / F(td)], [F(0), 1 / F(td)]]
+    T = [[F(1), -F(tc)], [F(0), F(1)]]
+    Ti = [[F(1), F(tc)], [F(0), F(1)]]
     for k in range(7):
         R = mat_mul(mat_mul(T, P), Ti)
-        want = [float(R[0][0]), float(R[0][1]), float(R[1][0]), float(R[1][1])]        # float(Fraction) rounds correctly
+        assert R[0][0] == R[1][1] and R[0][1] == -delta * R[1][0]                     # a I + b N, exactly
+        want = [float(R[0][0]), float(R[1][0]), float(R[0][1])]                       # float(Fraction) rounds correctly
         assert list(mp[k]) == want, (k, list(mp[k]), want)
-        if modal:                                            # a rotation-scaling of norm <= 1: nothing to cancel in the scans
-            assert abs(mp[k][0] - mp[k][3]) <= 1e-15 and abs(mp[k][1] + mp[k][2]) <= 1e-15
-            assert math.hypot(mp[k][0], mp[k][2]) <= 1.0
+        if delta > 0:                                                                 # a pole pair: rho^n (cos, sin / d): nothing to cancel
+            assert mp[k][0] ** 2 + float(delta) * mp[k][1] ** 2 <= 1.0 + 1e-12
         P = mat_mul(P, P)
 
 
@@ -77,18 +77,18 @@ def test_modal_start_states_match_the_sequential_recursion():
         y0 = b0 * x[i] + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2
         y[i] = y0
         x2, x1, y2, y1 = x1, x[i], y1, y0
-    mp, (tc, td, tid) = tables(a1, a2)
-    M = mp[0].reshape(2, 2)
+    mp, tc = tables(a1, a2)
+    M = np.array([[mp[0][0], mp[0][2]], [mp[0][1], mp[0][0]]])
     w = b0 * x + b1 * np.concatenate([[0], x[:-1]]) + b2 * np.concatenate([[0, 0], x[:-2]])
     W = w.reshape(-1, CHUNK)
     p1 = np.zeros(len(W)); p2 = np.zeros(len(W))
     for k in range(CHUNK):
         p1, p2 = W[:, k] - a1 * p1 - a2 * p2, p1
-    U = np.stack([p1 - tc * p2, td * p2], 1)
+    U = np.stack([p1 - tc * p2, p2], 1)
     s = np.zeros(2)
     worst = 0.0
     for c in range(len(W)):
-        got = (s[0] + tc * s[1] * tid, s[1] * tid)
+        got = (s[0] + tc * s[1], s[1])
         want = (y[c * CHUNK - 1], y[c * CHUNK - 2]) if c else (0.0, 0.0)
         worst = max(worst, abs(got[0] - want[0]), abs(got[1] - want[1]))
         s = M @ s + U[c]

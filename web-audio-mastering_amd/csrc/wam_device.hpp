@@ -29,12 +29,14 @@ constexpr int kTile = kThreads * C;    // 4096 samples
 // ---- host-prepared plans ---------------------------------------------------
 struct Biquad {            // y[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2] - a1 y[n-1] - a2 y[n-2]
   double b0, b1, b2, a1, a2;
-  // The scans run on the state in MODAL coordinates u = T (y[-1], y[-2]), T = [[1, -tc], [0, td]] (plan_tables.cpp): with the
-  // pole pair rho e^{+-i theta}, tc = rho cos(theta), td = rho sin(theta), the chunk transition becomes a rotation-scaling of
-  // norm <= 1 and its powers, products and weighted sums lose nothing - in the companion basis a 30 Hz section has
-  // |M^k| ~ 250 with cancellation everywhere, and the start states were off by 1e-9.  tid = 1 / td.  Real poles: T = identity.
-  double tc, td, tid;
-  double Mp[7][4];         // (T M T^-1)^(2^k), k = 0..6, M = transition of the state over one chunk (C samples)
+  // The scans run on the state in SHIFTED coordinates u = (y[-1] - tc y[-2], y[-2]), tc = -a1 / 2 = the real part of the
+  // poles (plan_tables.cpp).  There the one-sample transition is tc I + N with N = [[0, -delta], [1, 0]], N^2 = -delta I
+  // (delta = a2 - tc^2: rho^2 sin^2(theta) for a pole pair rho e^{+-i theta}, 0 for a double pole, negative for real poles), so
+  // every power is a I + b N = [[a, -delta b], [b, a]]: a rotation-scaling up to a diagonal scale, whose powers, products and
+  // weighted sums lose nothing.  In the companion basis (y[-1], y[-2]) a 30 Hz section has |M^k| ~ 250 with cancellation
+  // everywhere, and powers squared up in double put the chunk start states off by 1e-9.  Three numbers per power:
+  double tc;
+  double Mp[7][3];         // (a, b, -delta b) of the chunk transition (C samples) to the power 2^k, k = 0..6
 };
 struct OnePole {           // y[n] = c y[n-1] + u[n]
   double c;
@@ -228,26 +230,29 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
   return v;
 }
 
-__device__ __forceinline__ void mat2_mul(const double a[4], const double b[4], double o[4]) {
-  o[0] = a[0] * b[0] + a[1] * b[2]; o[1] = a[0] * b[1] + a[1] * b[3];
-  o[2] = a[2] * b[0] + a[3] * b[2]; o[3] = a[2] * b[1] + a[3] * b[3];
+// (a, b, b') of a product of two powers of one transition: (a1 I + b1 N)(a2 I + b2 N), N^2 = -delta I, b' = -delta b
+__device__ __forceinline__ void pow3_mul(const double x[3], const double y[3], double o[3]) {
+  o[0] = x[0] * y[0] + x[2] * y[1];
+  o[1] = x[0] * y[1] + x[1] * y[0];
+  o[2] = x[0] * y[2] + x[2] * y[0];
 }
 
 // M^lane from the power table (lane < 64)
-__device__ __forceinline__ void biquad_lane_power(const Biquad& q, int lane, double P[4]) {
-  P[0] = 1; P[1] = 0; P[2] = 0; P[3] = 1;
+__device__ __forceinline__ void biquad_lane_power(const Biquad& q, int lane, double P[3]) {
+  P[0] = 1; P[1] = 0; P[2] = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    if (lane & (1 << k)) { double t[4]; mat2_mul(q.Mp[k], P, t); P[0] = t[0]; P[1] = t[1]; P[2] = t[2]; P[3] = t[3]; }
+    if (lane & (1 << k)) { double t[3]; pow3_mul(q.Mp[k], P, t); P[0] = t[0]; P[1] = t[1]; P[2] = t[2]; }
   }
 }
-// The LDS table of a filter's lane powers is component-major, tab[64 c + lane] = (M^lane)[c]: a wavefront's 8-byte reads of
-// one component then touch consecutive banks (lane-major [lane][4] made them 8-way bank conflicts).
+// The LDS table of a filter's lane powers is component-major, tab[64 c + lane] = (a, b, b')[c] of M^lane: a wavefront's 8-byte
+// reads of one component then touch consecutive banks (lane-major made them bank conflicts).  [4][64] doubles are reserved
+// per filter by the callers; three rows are used.
 __device__ __forceinline__ void biquad_lane_power_table(const Biquad& q, int lane, double* tab) {
-  double P[4];
+  double P[3];
   biquad_lane_power(q, lane, P);
 #pragma unroll
-  for (int c = 0; c < 4; c++) tab[64 * c + lane] = P[c];
+  for (int c = 0; c < 3; c++) tab[64 * c + lane] = P[c];
 }
 __device__ __forceinline__ double onepole_lane_power(const OnePole& q, int lane) {
   double p = 1;
@@ -281,22 +286,22 @@ __device__ __forceinline__ void biquad_pre(double x[C], double xm1, double xm2, 
     const double y = w - a1 * p1 - a2 * p2;
     p2 = p1; p1 = y;
   }
-  double e0 = fma(-q.tc, p2, p1), e1 = q.td * p2;    // the chunk's zero-state end state in modal coordinates (struct Biquad)
+  double e0 = fma(-q.tc, p2, p1), e1 = p2;           // the chunk's zero-state end state in shifted coordinates (struct Biquad)
   const int lane = lane_id();
   m.S0 = Slds[0]; m.S1 = Slds[1];                    // (modal too) read before the caller's barrier; rewritten after it
   // weighted prefix sum of the end states: inside the rows of 16 lanes by DPP row shifts (uniform powers M^1, M^2, M^4, M^8) ...
 #define WAM_SCAN2_ROW(K, CTRL) { const double t0 = dpp_d<CTRL, 0xF>(0.0, e0), t1 = dpp_d<CTRL, 0xF>(0.0, e1); \
-    e0 += q.Mp[K][0] * t0 + q.Mp[K][1] * t1; e1 += q.Mp[K][2] * t0 + q.Mp[K][3] * t1; }
+    e0 += q.Mp[K][0] * t0 + q.Mp[K][2] * t1; e1 += q.Mp[K][1] * t0 + q.Mp[K][0] * t1; }
   WAM_SCAN2_ROW(0, 0x111) WAM_SCAN2_ROW(1, 0x112) WAM_SCAN2_ROW(2, 0x114) WAM_SCAN2_ROW(3, 0x118)
   {
     // ... then the aggregate of the row(s) below reaches a lane through M^(distance to that aggregate's lane): M^((lane & 15) + 1) for
     // the previous row's lane 15, M^(lane - 31) for lane 31 - both entries of the M^lane table
     const double* Pa = Plds + ((lane & 15) + 1);
     const double ta0 = dpp_d<0x142, 0xA>(0.0, e0), ta1 = dpp_d<0x142, 0xA>(0.0, e1);
-    e0 += Pa[0] * ta0 + Pa[64] * ta1; e1 += Pa[128] * ta0 + Pa[192] * ta1;
+    { const double pa = Pa[0], pb = Pa[64], pc = Pa[128]; e0 += pa * ta0 + pc * ta1; e1 += pb * ta0 + pa * ta1; }
     const double* Pb = Plds + (lane >= 32 ? lane - 31 : 0);
     const double tb0 = dpp_d<0x143, 0xC>(0.0, e0), tb1 = dpp_d<0x143, 0xC>(0.0, e1);
-    e0 += Pb[0] * tb0 + Pb[64] * tb1; e1 += Pb[128] * tb0 + Pb[192] * tb1;
+    { const double pa = Pb[0], pb = Pb[64], pc = Pb[128]; e0 += pa * tb0 + pc * tb1; e1 += pb * tb0 + pa * tb1; }
   }
   if (lane == 63) { ldsw[0] = e0; ldsw[1] = e1; }
   m.x0 = dpp_d<0x138, 0xF>(0.0, e0); m.x1 = dpp_d<0x138, 0xF>(0.0, e1);
@@ -311,16 +316,16 @@ __device__ __forceinline__ void biquad_post(double x[C], const Biquad& q, const 
 #pragma unroll
   for (int w = 0; w < kWaves; w++) {
     const double c0 = lds4[2 * w], c1 = lds4[2 * w + 1];
-    const double n0 = q.Mp[6][0] * w0 + q.Mp[6][1] * w1 + c0;
-    const double n1 = q.Mp[6][2] * w0 + q.Mp[6][3] * w1 + c1;
+    const double n0 = q.Mp[6][0] * w0 + q.Mp[6][2] * w1 + c0;
+    const double n1 = q.Mp[6][1] * w0 + q.Mp[6][0] * w1 + c1;
     w0 = n0; w1 = n1;
     if (w + 1 == wave) { my0 = w0; my1 = w1; }
   }
   if (threadIdx.x == 0) { Slds[0] = w0; Slds[1] = w1; }
   const double* P = Plds + lane;
-  const double u0 = m.x0 + P[0] * my0 + P[64] * my1;
-  const double u1 = m.x1 + P[128] * my0 + P[192] * my1;
-  s1 = u1 * q.tid;                                   // back to (y[-1], y[-2])
+  const double pa = P[0], pb = P[64], pc = P[128];
+  const double u0 = m.x0 + pa * my0 + pc * my1;
+  s1 = m.x1 + pb * my0 + pa * my1;                   // back to (y[-1], y[-2]): y[-2] is the second coordinate itself
   s0 = fma(q.tc, s1, u0);
   double p1 = s0, p2 = s1;
 #pragma unroll

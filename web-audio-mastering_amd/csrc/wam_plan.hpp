@@ -13,14 +13,10 @@ inline void mat2_mul_h(const double a[4], const double b[4], double o[4]) {
   std::memcpy(o, t, sizeof(t));
 }
 
-// Fill the scan tables of a biquad from its five coefficients: the modal transform and the powers of the chunk transition in
-// modal coordinates, evaluated in quadruple precision on the host (plan_tables.cpp says why).
-extern "C" void wam_biquad_scan_tables(double a1, double a2, int chunk, double Mp[7][4], double T3[3]);
-inline void finish_biquad(Biquad& q) {
-  double T3[3];
-  wam_biquad_scan_tables(q.a1, q.a2, C, q.Mp, T3);
-  q.tc = T3[0]; q.td = T3[1]; q.tid = T3[2];
-}
+// Fill the scan tables of a biquad from its five coefficients: the shift of the state coordinates and the powers of the chunk
+// transition there, evaluated in quadruple precision on the host (plan_tables.cpp says why).
+extern "C" void wam_biquad_scan_tables(double a1, double a2, int chunk, double Mp[7][3], double* tc);
+inline void finish_biquad(Biquad& q) { wam_biquad_scan_tables(q.a1, q.a2, C, q.Mp, &q.tc); }
 inline Biquad make_biquad(double b0, double b1, double b2, double a1, double a2) {
   Biquad q; q.b0 = b0; q.b1 = b1; q.b2 = b2; q.a1 = a1; q.a2 = a2; finish_biquad(q); return q;
 }
