@@ -211,6 +211,29 @@ __global__ __launch_bounds__(256) void k_pcm16(const float* __restrict__ in, int
 
 // ------------------------------------------------------------------ spectrogram STFT
 struct StftRow { int bin1, bin2; double frac; int valid; };
+
+// 10 log10(pw + 1e-24) + add_db, floored at -144 (spectrogram.js:135-141), for pw >= 0 finite.  ln by the mantissa's atanh series
+// (m in [sqrt(1/2), sqrt(2)): s = (m - 1) / (m + 1), |s| <= 0.172, odd series to s^17: truncation 2e-15 relative), ~30 instructions
+// against ~90 for ocml's log10; the result is an f32 store, and all three STFT kernels share this function (they must agree to the bit).
+__device__ __forceinline__ float stft_db(double pw, double add_db) {
+  const double x = pw + 1e-24;
+  double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
+  int E = __builtin_amdgcn_frexp_exp(x);
+  if (m < 0.70710678118654752) { m *= 2.0; E -= 1; }
+  const double sq = div_fast(m - 1.0, m + 1.0), s2 = sq * sq;
+  double p = 1.0 / 17.0;
+  p = fma(p, s2, 1.0 / 15.0);
+  p = fma(p, s2, 1.0 / 13.0);
+  p = fma(p, s2, 1.0 / 11.0);
+  p = fma(p, s2, 1.0 / 9.0);
+  p = fma(p, s2, 1.0 / 7.0);
+  p = fma(p, s2, 1.0 / 5.0);
+  p = fma(p, s2, 1.0 / 3.0);
+  p = fma(p, s2, 1.0);
+  // 10 log10(x) = E 10 log10(2) + (20 / ln 10) s p
+  const double db = fma((double)E, 3.01029995663981195214, 8.68588963806503655303 * sq * p) + add_db;
+  return f32r(db < -144 ? -144.0 : db);
+}
 __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int nch, int64_t n, int nfft, int bits, int hop, int64_t nframes,
                                               const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
                                               double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols) {
@@ -247,8 +270,7 @@ __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int 
     }
     for (int i = threadIdx.x; i < half; i += 256) {
       const double pw = (double)re[i] * (double)re[i] + (double)im[i] * (double)im[i];
-      const double db = 10 * log10(pw + 1e-24) + add_db;              // spectrogram.js:135-141
-      const float v = f32r(db < -144 ? -144.0 : db);
+      const float v = stft_db(pw, add_db);                            // spectrogram.js:135-141
       sp[i] = v;
       out_db[f * half + i] = v;
     }
@@ -353,8 +375,7 @@ __global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in,
       for (int m = 0; m < RL / 2; m++) {               // bins below N / 2
         const int i = u + m * (N / RL);
         const double pw = (double)w4[m].x * (double)w4[m].x + (double)w4[m].y * (double)w4[m].y;
-        const double db = 10 * log10(pw + 1e-24) + add_db;              // spectrogram.js:135-141
-        const float o = f32r(db < -144 ? -144.0 : db);
+        const float o = stft_db(pw, add_db);                            // spectrogram.js:135-141
         sp[i] = o;
         out_db[f * half + i] = o;
       }
@@ -366,6 +387,202 @@ __global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in,
       if (r.valid) o = (double)sp[r.bin1] + ((double)sp[r.bin2] - (double)sp[r.bin1]) * r.frac;   // spectrogram.js:196-200
       cols[f * 256 + t] = f32r(o);
       __syncthreads();
+    }
+  }
+}
+
+
+// ---- the 4096-point transform, one WAVEFRONT per frame ------------------------------------------------------------------
+// BASELINE configs[4] (4096 / hop 1024 over the corpus).  A lane holds 64 points: positions 64 lane .. 64 lane + 63 of the
+// bit-reversed array for stages 1-6 (all in registers), then - after ONE transposition through a wavefront-private LDS buffer -
+// positions lane + 64 m for stages 7-12.  No workgroup barrier inside the frame loop (the eight wavefronts of a workgroup only
+// share the read-only twiddle table); a wavefront that waits for its loads leaves its SIMD to the other resident one.
+// Every butterfly is the expression of spectrogram.js:238-256 on the same operands with the same f32 stores, so the result
+// equals k_stft's to the bit; what is NOT computed is what cannot change a bit:
+//   * twiddle (1, -0) (k = 0 of every stage): tr = xr, ti = xi exactly, and the sum of two f32 values rounded to double and then
+//     to f32 is the f32 sum (double rounding is innocuous for +, -, x when the wide format has >= 2 p + 2 bits: 53 >= 50);
+//   * the imaginary parts are exactly zero until stage 2's k = 1 butterflies write the first non-zero ones;
+//   * mono mix and window, f32(0.5 (a + b)) and f32(m w): the same theorem (0.5 x is exact);
+//   * the twiddles of stages 1-6 are the same 32 numbers for every lane: scalar loads of a pre-widened table.
+constexpr int kSwN = 4096, kSwPad = kSwN + 64, kSwWaves = 4;
+__host__ __device__ constexpr int brev6c(int m) { return ((m & 1) << 5) | ((m & 2) << 3) | ((m & 4) << 1) | ((m & 8) >> 1) | ((m & 16) >> 3) | ((m & 32) >> 5); }
+__device__ __forceinline__ void stft_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// stage S (1..6) on the lane's 64 consecutive positions; IMZ: every imaginary input of the stage is zero
+template <int S, bool IMZ>
+__device__ __forceinline__ void stft_local_stage(float re[64], float im[64], const double2* __restrict__ tw6) {
+#pragma clang fp contract(off)       // an f32 sum must not be fused with the f32 product that made its operand (that product IS rounded)
+  constexpr int h = 1 << (S - 1);
+  int done = 0;
+#pragma unroll
+  for (int m = 0; m < 64; m++) {
+    if (m & h) continue;
+    // a few butterflies in flight, not all thirty-two: their widened operands would not fit beside the 128 registers of data
+    if ((done++ & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    const int kk = m & (h - 1);
+    if (kk == 0) {
+      const float ar = re[m], xr = re[m + h];
+      re[m] = ar + xr; re[m + h] = ar - xr;
+      if (!IMZ) { const float ai = im[m], xi = im[m + h]; im[m] = ai + xi; im[m + h] = ai - xi; }
+    } else {
+      const double2 w = tw6[kk << (6 - S)];              // (cos, sin)[kk 4096 / 2^S], widened on the host: a scalar load
+      const double xr = re[m + h], ar = re[m];
+      double tr, ti, ai;
+      if (IMZ) { tr = xr * w.x; ti = xr * w.y; ai = 0.0; }             // xi = 0: its two products are zeros
+      else { const double xi = im[m + h]; tr = xr * w.x - xi * w.y; ti = xr * w.y + xi * w.x; ai = im[m]; }
+      re[m + h] = f32r(ar - tr); im[m + h] = f32r(ai - ti);
+      re[m] = f32r(ar + tr); im[m] = f32r(ai + ti);
+    }
+  }
+}
+// stage 7 + J on positions lane + 64 m: butterfly (m, m + 2^J) has k = lane + 64 (m mod 2^J), table stride 2^(5 - J)
+template <int J>
+__device__ __forceinline__ void stft_cross_stage(float re[64], float im[64], const float2* twl, int lane) {
+  constexpr int h = 1 << J;
+#pragma unroll
+  for (int t = 0; t < h; t++) {
+    const float2 wf = twl[(lane + 64 * t) << (5 - J)];
+    const double cw = wf.x, sw = wf.y;
+    int done = 0;
+#pragma unroll
+    for (int m = t; m < 64; m += 2 * h) {
+      if ((done++ & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const double xr = re[m + h], xi = im[m + h];
+      const double tr = xr * cw - xi * sw;
+      const double ti = xr * sw + xi * cw;
+      const double ar = re[m], ai = im[m];
+      re[m + h] = f32r(ar - tr); im[m + h] = f32r(ai - ti);
+      re[m] = f32r(ar + tr); im[m] = f32r(ai + ti);
+    }
+  }
+}
+template <int NCHT, bool COLS>
+__global__ __launch_bounds__(64 * kSwWaves) void k_stft_wave(const float* __restrict__ in, int64_t n, int hop, int64_t nframes,
+                                                             const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
+                                                             const double2* __restrict__ tw6, double add_db, float* __restrict__ out_db,
+                                                             const StftRow* __restrict__ rows, float* __restrict__ cols) {
+#pragma clang fp contract(off)       // (see stft_local_stage; the double butterflies' products are exact, fused or not)
+  __shared__ float2 twl[kSwN / 2];
+  __shared__ float winl[kSwN];
+  __shared__ float exch[kSwWaves][kSwPad];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int i = threadIdx.x; i < kSwN / 2; i += 64 * kSwWaves) twl[i] = make_float2(cosT[i], sinT[i]);
+  for (int i = threadIdx.x; i < kSwN; i += 64 * kSwWaves) winl[i] = win[i];
+  __syncthreads();
+  float* buf = exch[wv];
+  in += (int64_t)blockIdx.y * NCHT * n;
+  out_db += (int64_t)blockIdx.y * nframes * (kSwN / 2);
+  if (COLS) cols += (int64_t)blockIdx.y * nframes * 256;
+  const unsigned rl = __brev((unsigned)lane) >> 26;
+  // One wavefront per SIMD (frame, widened operands and the allocator's slack take ~430 of the 512 registers), so nothing else hides
+  // a load: the NEXT frame's samples are requested when this frame's last stage is done - its 128 data registers are about to die -
+  // and arrive while the dB values are computed; the stores that follow are younger than those loads, so the wait at the top of
+  // the loop does not include them.
+  const int64_t fstep = (int64_t)gridDim.x * kSwWaves;
+  int64_t f = (int64_t)blockIdx.x * kSwWaves + wv;
+  // Channel 0 lands in registers; channel 1 would be 64 more, which the allocator does not fit, so it goes straight from memory
+  // into this wavefront's exchange buffer (global_load_lds: no register touched), which is idle from the transposition to the
+  // next frame's: sample (lane, m) at buf[64 m + lane].  (Issued after the frame's last LDS read: the compiler orders every LDS
+  // read behind outstanding loads of this kind.)
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+  float pa[64];
+  if (f < nframes) {
+    const float* xa = in + f * hop;                    // uniform bases (scalar registers) + 32-bit lane offsets: four address registers, not 128
+    const float* xb = xa + n;
+#pragma unroll
+    for (int m = 0; m < 64; m++) {
+      const unsigned i = rl + (unsigned)(brev6c(m) << 6);
+      pa[m] = xa[i];
+      if (NCHT >= 2) __builtin_amdgcn_global_load_lds((gptr_t)(xb + i), (lptr_t)(buf + 64 * m), 4, 0, 0);
+    }
+  }
+  for (; f < nframes; f += fstep) {
+    // The window, the twiddles of both halves and the row table do not depend on the frame: left alone, the compiler hoists their
+    // ~250 registers of loads out of this loop and spills.  An opaque zero added to the indices keeps each load where it is used.
+    // (Likewise every index derived from the lane number: hoisted, the 190 of them are spilled; recomputed, each costs one add.)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    unsigned rlo = rl;
+    int lo = lane;
+    asm volatile("" : "+v"(rlo), "+v"(lo));
+    const float* winf = winl + zero;
+    const double2* tw6f = tw6 + zero;
+    const float2* twlf = twl + zero;
+    float re[64], im[64];
+    // position 64 lane + m of the bit-reversed array holds sample brev12(64 lane + m) = 64 brev6(m) + brev6(lane)  (spectrogram.js:121-123, :222-235)
+#pragma unroll
+    for (int m = 0; m < 64; m++) {
+      const unsigned i = rlo + (unsigned)(brev6c(m) << 6);
+      float mm;
+      if (NCHT >= 2) mm = 0.5f * (pa[m] + buf[64 * m + lo]); else mm = pa[m];
+      re[m] = mm * winf[i];
+      im[m] = 0.0f;
+    }
+    stft_local_stage<1, true>(re, im, tw6f);
+    stft_local_stage<2, true>(re, im, tw6f);
+    stft_local_stage<3, false>(re, im, tw6f);
+    stft_local_stage<4, false>(re, im, tw6f);
+    stft_local_stage<5, false>(re, im, tw6f);
+    stft_local_stage<6, false>(re, im, tw6f);
+    // transposition: position p sits at buf[p + (p >> 6)] (one pad per 64: both directions touch 64 different banks)
+    stft_wave_sync();                                    // the previous frame's reads of buf precede these writes
+#pragma unroll
+    for (int m = 0; m < 64; m++) buf[65 * lo + m] = re[m];
+    stft_wave_sync();
+#pragma unroll
+    for (int m = 0; m < 64; m++) re[m] = buf[lo + 65 * m];
+    stft_wave_sync();
+#pragma unroll
+    for (int m = 0; m < 64; m++) buf[65 * lo + m] = im[m];
+    stft_wave_sync();
+#pragma unroll
+    for (int m = 0; m < 64; m++) im[m] = buf[lo + 65 * m];
+    stft_cross_stage<0>(re, im, twlf, lo);
+    stft_cross_stage<1>(re, im, twlf, lo);
+    stft_cross_stage<2>(re, im, twlf, lo);
+    stft_cross_stage<3>(re, im, twlf, lo);
+    stft_cross_stage<4>(re, im, twlf, lo);
+    stft_cross_stage<5>(re, im, twlf, lo);
+    float* o = out_db + f * (kSwN / 2) + lo;
+    if (f + fstep < nframes) {                           // the next frame's samples: in flight during the dB stage
+      const float* xa = in + (f + fstep) * hop;
+      const float* xb = xa + n;
+      if (NCHT >= 2 && !COLS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the transposition's reads of buf have returned
+#pragma unroll
+      for (int m = 0; m < 64; m++) {
+        const unsigned i = rlo + (unsigned)(brev6c(m) << 6);
+        pa[m] = xa[i];
+        if (NCHT >= 2 && !COLS) __builtin_amdgcn_global_load_lds((gptr_t)(xb + i), (lptr_t)(buf + 64 * m), 4, 0, 0);
+      }
+    }
+    if (COLS) stft_wave_sync();                          // the reads of buf above precede the writes below
+#pragma unroll
+    for (int m = 0; m < 32; m++) {                       // bins lane + 64 m < 2048
+      if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const double pw = (double)re[m] * (double)re[m] + (double)im[m] * (double)im[m];
+      const float v = stft_db(pw, add_db);
+      o[64 * m] = v;
+      if (COLS) buf[lo + 64 * m] = v;
+    }
+    if (COLS) {
+      stft_wave_sync();
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const StftRow r = rows[lo + 64 * q];
+        double v = -144;
+        if (r.valid) v = (double)buf[r.bin1] + ((double)buf[r.bin2] - (double)buf[r.bin1]) * r.frac;   // spectrogram.js:196-200
+        cols[f * 256 + lo + 64 * q] = f32r(v);
+      }
+      if (NCHT >= 2 && f + fstep < nframes) {            // buf held the spectrum until here: channel 1 of the next frame only now
+        const float* xb = in + (f + fstep) * hop + n;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 64; m++) __builtin_amdgcn_global_load_lds((gptr_t)(xb + rlo + (unsigned)(brev6c(m) << 6)), (lptr_t)(buf + 64 * m), 4, 0, 0);
+      }
     }
   }
 }
@@ -729,11 +946,29 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
   if (ntracks >= 64 && bx > 128) bx = 128;                               // enough workgroups from the track dimension
   const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
   const float* ct = tabs.as<float>(); const float* st = ct + nfft; const float* wn = ct + 2 * nfft;
+  DevBuf tw6b;
+  if (nfft == 4096) {                                                    // stages 1-6 of the wavefront kernel: (cos, sin)[64 k], k < 32, widened
+    std::vector<double> t6(64);
+    for (int k = 0; k < 32; k++) { t6[2 * k] = (double)tab[64 * k]; t6[2 * k + 1] = (double)tab[nfft + 64 * k]; }
+    rc = tw6b.alloc(sizeof(double) * 64); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(tw6b.p, t6.data(), sizeof(double) * 64, hipMemcpyHostToDevice, stream));
+    WAM_HIP(hipStreamSynchronize(stream));                               // t6 is a local
+  }
+  const int variant = (int)tuning().stft_literal;                        // 0: fastest kernel for the size; 1: the literal loop nest; 2: the register-blocked workgroup kernel
   const int prof_ticket = prof_begin("k_stft", stream);
-  if (nfft == 4096 && !tuning().stft_literal)
+  if (nfft == 4096 && variant == 0) {
+    int64_t gx = (nframes + kSwWaves - 1) / kSwWaves;
+    if (gx > 64) gx = 64;
+    if (ntracks < 64) { const int64_t want = (2048 + ntracks - 1) / ntracks; gx = (nframes + kSwWaves - 1) / kSwWaves; if (gx > want) gx = want; }
+#define WAM_STFT_WAVE(NC, CL) hipLaunchKernelGGL((k_stft_wave<NC, CL>), dim3((unsigned)gx, (unsigned)ntracks), dim3(64 * kSwWaves), 0, stream, in_dev, n, hop, nframes, \
+                                                 ct, st, wn, (const double2*)tw6b.as<double2>(), add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev)
+    if (nch == 2) { if (cols_dev) WAM_STFT_WAVE(2, true); else WAM_STFT_WAVE(2, false); }
+    else { if (cols_dev) WAM_STFT_WAVE(1, true); else WAM_STFT_WAVE(1, false); }
+#undef WAM_STFT_WAVE
+  } else if (nfft == 4096 && variant != 1)
     hipLaunchKernelGGL(k_stft_fast<12>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
                        out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
-  else if (nfft == 2048 && !tuning().stft_literal)
+  else if (nfft == 2048 && variant != 1)
     hipLaunchKernelGGL(k_stft_fast<11>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
                        out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
   else
