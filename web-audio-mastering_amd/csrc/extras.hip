@@ -420,8 +420,9 @@ __device__ __forceinline__ void stft_local_stage(float re[64], float im[64], con
 #pragma unroll
   for (int m = 0; m < 64; m++) {
     if (m & h) continue;
-    // a few butterflies in flight, not all thirty-two: their widened operands would not fit beside the 128 registers of data
-    if ((done++ & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    // eight butterflies in flight, not all thirty-two: their widened operands would not fit beside the 128 registers of data (measured per
+    // 1,024 tracks: 4 at a time 157 ms, 8: 152.5, 16: 157)
+    if ((done++ & 7) == 0) __builtin_amdgcn_sched_barrier(0);
     const int kk = m & (h - 1);
     if (kk == 0) {
       const float ar = re[m], xr = re[m + h];
@@ -438,18 +439,42 @@ __device__ __forceinline__ void stft_local_stage(float re[64], float im[64], con
     }
   }
 }
-// stage 7 + J on positions lane + 64 m: butterfly (m, m + 2^J) has k = lane + 64 (m mod 2^J), table stride 2^(5 - J)
+// stage 7 + J on positions lane + 64 m: butterfly (m, m + 2^J) has k = lane + 64 (m mod 2^J), table stride 2^(5 - J).
+// Thirty-two butterflies, four at a time between scheduling fences: butterfly b has t = b mod h, m = 2 h (b div h) + t; the four
+// twiddle reads of a group go out together at its start (one LDS round trip per group, not one per butterfly in the last stages).
+#ifndef WAM_STFT_GROUP_FROM
+#define WAM_STFT_GROUP_FROM 6
+#endif
 template <int J>
 __device__ __forceinline__ void stft_cross_stage(float re[64], float im[64], const float2* twl, int lane) {
   constexpr int h = 1 << J;
+  if constexpr (J < WAM_STFT_GROUP_FROM) {               // few twiddles: one read per twiddle, its butterflies four at a time
 #pragma unroll
-  for (int t = 0; t < h; t++) {
-    const float2 wf = twl[(lane + 64 * t) << (5 - J)];
-    const double cw = wf.x, sw = wf.y;
-    int done = 0;
+    for (int t = 0; t < h; t++) {
+      const float2 wf = twl[(lane + 64 * t) << (5 - J)];
+      const double cw = wf.x, sw = wf.y;
+      int done = 0;
 #pragma unroll
-    for (int m = t; m < 64; m += 2 * h) {
-      if ((done++ & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      for (int m = t; m < 64; m += 2 * h) {
+        if ((done++ & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        const double xr = re[m + h], xi = im[m + h];
+        const double tr = xr * cw - xi * sw;
+        const double ti = xr * sw + xi * cw;
+        const double ar = re[m], ai = im[m];
+        re[m + h] = f32r(ar - tr); im[m + h] = f32r(ai - ti);
+        re[m] = f32r(ar + tr); im[m] = f32r(ai + ti);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int b = 4 * g + q, t = b % h, m = 2 * h * (b / h) + t;
+      const float2 wf = twl[(lane + 64 * t) << (5 - J)];
+      const double cw = wf.x, sw = wf.y;
       const double xr = re[m + h], xi = im[m + h];
       const double tr = xr * cw - xi * sw;
       const double ti = xr * sw + xi * cw;
