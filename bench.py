@@ -75,7 +75,25 @@ KERNEL_BYTES = {
     "k_lim_gain": 8,       # read x + transient map, write gain envelope
     "k_lim_apply": 10,     # read x + envelope, write y
 }
-VALU_PEAK = 256 * 4 * 64 * 2.4e9 / 4       # f64 VALU lane-instructions / s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz, one issue per 4 cycles
+NOMINAL_MHZ = 2400.0
+
+
+def valu_peak(mhz):
+    """f64 VALU lane-instructions / s: 256 CU x 4 SIMD x 64 lanes x clock, one issue per 4 cycles."""
+    return 256 * 4 * 64 * mhz * 1e6 / 4
+
+
+def source_digest():
+    """sha1 over the kernel sources (csrc/*.hip, *.hpp, *.cpp): what a committed PMC summary was taken from.  The GPU box has no
+    .git, so this - not a commit hash - is what bench.py can compare at run time; profiles/ingest.py records both."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "web-audio-mastering_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp")) + glob.glob(os.path.join(src, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 GROUP = 256      # tracks per render group inside the library (csrc/chain_api.hip): one launch of a chain kernel covers a group
 # kernels that go through a group in several launches (channels that fit the de-harsh magnitude scratch): the committed PMC figures
 # are per PASS over the launch's tracks (profiles/pmc_summary.py sums their launches)
@@ -114,18 +132,34 @@ def _pmc_rows():
     import csv
     import glob
     rows, tracks = {}, {}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")) + glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_meter_summary.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")) + glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_meter_summary.csv")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_stft_summary.csv")), key=os.path.basename)
     for path in files:                                    # later rounds overwrite earlier ones
         with open(path) as f:
             rs = list(csv.DictReader(f))
-        meta = [r for r in rs if r["kernel"] == "#tracks_per_launch"]
-        ref = float(meta[0]["launches"]) if meta else None
+        meta = {r["kernel"]: r["launches"] for r in rs if r["kernel"].startswith("#")}
+        ref = float(meta["#tracks_per_launch"]) if "#tracks_per_launch" in meta else None
         for r in rs:
             if not r["kernel"].startswith("#"):
                 rows[r["kernel"]] = r
                 tracks[r["kernel"]] = ref
                 r["_file"] = os.path.basename(path)
+                r["_commit"] = meta.get("#commit")
+                r["_digest"] = meta.get("#source_digest")
     return rows, tracks
+
+
+def pmc_provenance(rows, kernels):
+    """Which committed summaries the instruction counts / traffic of `kernels` come from, and whether the kernel sources have
+    changed since they were taken."""
+    now = source_digest()
+    files = {}
+    for k_ in kernels:
+        r = rows.get(k_)
+        if r:
+            files[r["_file"]] = {"commit": r.get("_commit"), "source_digest": r.get("_digest"),
+                                 "sources_unchanged": (r.get("_digest") == now) if r.get("_digest") else None}
+    return {"source_digest_now": now, "files": files}
 
 
 def pmc_traffic(kernel, tracks_per_launch, rows=None, tracks=None):
@@ -253,10 +287,16 @@ def free_port():
     return p
 
 
+LAUNCH_TIMEOUT_S = 1500.0      # default limit of a self-launched job (WAM_BENCH_TIMEOUT overrides): a default bench step set is ~1 min per rank
+
+
 def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
     """Start `n` rank processes of `script` (default: this file) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
     set, relay rank 0's stdout to ours and every rank's stderr (and the other ranks' stdout) to stderr with a rank prefix.
-    The parent never initialises the GPU; children are fresh interpreters.  Returns the worst exit code."""
+    The parent never initialises the GPU; children are fresh interpreters.  Returns the worst exit code; after `timeout`
+    seconds (default LAUNCH_TIMEOUT_S) the ranks still running are named on stderr and killed, and the code is 124."""
+    if timeout is None:
+        timeout = float(os.environ.get("WAM_BENCH_TIMEOUT", LAUNCH_TIMEOUT_S))
     script = script or os.path.abspath(__file__)
     port = free_port()
     procs = []
@@ -291,6 +331,8 @@ def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
                     for q in pending:            # one rank failed: the others would wait in a collective for ever
                         q.terminate()
         if deadline and time.time() > deadline:
+            stuck = [procs.index(q) for q in pending]
+            print(f"bench.py: rank(s) {stuck} still running after {timeout:.0f} s (stuck in rendezvous or a collective?): killed", file=sys.stderr, flush=True)
             for q in pending:
                 q.kill()
             worst = worst or 124
@@ -451,23 +493,31 @@ def main():
     dt = time.perf_counter() - t0
     prof = profile_read()
     wam.lib().wam_profile_enable(0)
+    rank_ms = [float(v) for v in wam_dist.gather_track_scalars(torch.tensor([[dt / args.steps * 1e3]], dtype=torch.float64), world, comm)[:, 0].tolist()] if world > 1 else [dt / args.steps * 1e3]
     dt = wam_dist.max_over_ranks(dt, comm)
     # per-track scalars of every shard, in global track order (the only data that leaves a rank)
     if chain_like:
         local = [[r.lufs, r.true_peak_db, r.lufs_in, r.gain_db] for r in res]
         k = 4
     elif wl == "stft":
-        local = [[float(spec[t].max()), float(spec[t, :, 1:].float().mean())] for t in range(min(T, 4))] + [[0.0, 0.0]] * max(0, T - 4)
+        local = [[float(spec[t].max()), float(spec[t, :, 1:].float().mean())] for t in range(min(T, 4))] + [[float("nan"), float("nan")]] * max(0, T - 4)
         k = 2
     else:
         local = [[float(a), float(b)] for a, b in zip(res[0], res[1])]
         k = 2
     table = wam_dist.gather_track_scalars(torch.tensor(local, dtype=torch.float64).reshape(T, k), total, comm)
 
+    # the shader clock the chip holds under f64 load, measured right behind the timed region (the chip is as warm as it gets)
+    clock_mhz = None
+    if rank == 0:
+        mhz = C.c_double(0)
+        if hasattr(wam.lib(), "wam_probe_shader_clock") and wam.lib().wam_probe_shader_clock(C.c_double(25.0), C.byref(mhz)) == 0 and mhz.value > 0:
+            clock_mhz = mhz.value
     if rank == 0:
         audio_s = total * SECONDS * args.steps
         ms_per_step = dt / args.steps * 1e3
         rows, rtracks = _pmc_rows()
+        VALU_PEAK = valu_peak(clock_mhz or NOMINAL_MHZ)
         # dominant kernel by total device time (rank 0's shard; every rank runs the same kernels on its own tracks)
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roofline = None
@@ -479,30 +529,37 @@ def main():
             launches_per_step = cnt / args.steps
             avg_ms = total_ms / cnt
             bpsc = KERNEL_BYTES.get(name)
+            pmc_name = name
             if name == "k_stft":
                 bpsc = 12 / NCH                     # 12 B per MONO sample: 4 read (both channels: 8) ... stated per sample-channel
+                pmc_name = "k_stft_wave"            # the profiling hook's name covers the three STFT kernels; the default 4096-point one is this
             if bpsc is not None:
                 alg_bytes = bpsc * units_per_launch
                 achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                            "frac": achieved / 8000.0, "traffic": pmc_traffic(name, tracks_per_launch, rows, rtracks), "avg_launch_ms": avg_ms,
+                            "frac": achieved / 8000.0, "traffic": pmc_traffic(pmc_name, tracks_per_launch, rows, rtracks), "avg_launch_ms": avg_ms,
                             "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_bytes,
                             "note": ("the chain kernels are bound by f64 VALU issue, not HBM (DESIGN.md 5-6): see roofline_valu") if chain_like else
                                     ("two f64 K-weighting biquad scans + the 4-point peak interpolation per 4-byte sample: VALU-bound "
-                                     "(DESIGN.md 5)" if wl == "meter" else "f32 butterflies in LDS; see DESIGN.md 5")}
+                                     "(DESIGN.md 5)" if wl == "meter" else
+                                     "radix-2 butterflies in double with an f32 store after each (the reference's arithmetic), one wavefront per frame: "
+                                     "VALU-bound, see roofline_valu and DESIGN.md 5")}
             else:
                 roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                             "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step}
-            ipu = pmc_instr(name, rows)
+            ipu = pmc_instr(pmc_name, rows)
             if ipu is not None:
-                ach = ipu * units_per_launch / (avg_ms * 1e-3)
-                roofline_valu = {"bound": "valu_f64", "kernel": name, "instr_per_unit": ipu, "unit_of_work": "sample-channel", "units_per_launch": units_per_launch,
-                                 "avg_launch_ms": avg_ms, "achieved": ach, "peak": VALU_PEAK, "unit": "lane-instr/s", "frac": ach / VALU_PEAK,
-                                 "source": rows[name]["_file"]}
+                # (the STFT summary counts per MONO sample: its units are tracks x n)
+                units_v = units_per_launch // NCH if wl == "stft" else units_per_launch
+                ach = ipu * units_v / (avg_ms * 1e-3)
+                roofline_valu = {"bound": "valu_f64", "kernel": pmc_name, "instr_per_unit": ipu, "unit_of_work": "mono sample" if wl == "stft" else "sample-channel",
+                                 "units_per_launch": units_v, "avg_launch_ms": avg_ms, "achieved": ach, "peak": VALU_PEAK, "unit": "lane-instr/s", "frac": ach / VALU_PEAK,
+                                 "shader_clock_mhz": clock_mhz, "peak_at_nominal_2400_mhz": valu_peak(NOMINAL_MHZ),
+                                 "source": rows[pmc_name]["_file"]}
         kernels = {k_: {"launches": v[0], "total_ms": round(v[1], 3)} for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         kernel_ms_per_step = sum(v[1] for v in prof.values()) / args.steps
         chain_bytes = (16 if chain_like else (6 if wl == "stft" else 4)) * T * NCH * N
-        if roofline_valu is not None and kernel_ms_per_step > 0:
+        if roofline_valu is not None and kernel_ms_per_step > 0 and wl != "stft":
             # the whole step against the same peak: sum over kernels of (instructions per unit x units the kernel covered in a step)
             instr = 0.0
             missing = []
@@ -522,7 +579,7 @@ def main():
             tb_, ok = 0.0, True
             groups_per_step = -(-T // GROUP) if chain_like else 1
             for k_, (cnt, _) in prof.items():
-                b = pmc_traffic(k_, tracks_per_launch, rows, rtracks)
+                b = pmc_traffic("k_stft_wave" if k_ == "k_stft" else k_, tracks_per_launch, rows, rtracks)
                 if b is None:
                     ok = False
                     continue
@@ -541,7 +598,9 @@ def main():
             "metric": ("x realtime (audio-s/s) full master chain+LUFS" if chain_like else
                        "x realtime (audio-s/s) 4096-pt STFT hop 1024" if wl == "stft" else "x realtime (audio-s/s) LUFS+true-peak meter"),
             "value": audio_s / dt, "unit": "x realtime (audio-s/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            # the arithmetic type of the path: IEEE double with f32 stores (the reference's JavaScript numbers over Float32Arrays)
+            "dtype": "f64 (f32 stores after every butterfly)" if wl == "stft" else "f64",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, numbers meaningless)" if rehearsal else ""),
             "config": {"workload": cfg_workload, "tracks_total": total, "tracks_per_gpu": T if scaling == "weak" else None,
                        "tracks_rank0": T, "seconds_per_track": SECONDS, "sample_rate": SR, "channels": NCH,
@@ -555,10 +614,18 @@ def main():
             "chain_traffic_bytes": traffic_step,
             "kernel_ms_per_step": kernel_ms_per_step,
             "kernels": kernels,
+            "shader_clock_mhz": clock_mhz,
+            "pmc_provenance": pmc_provenance(rows, ["k_stft_wave" if k_ == "k_stft" else k_ for k_ in prof]),
         }
+        if world > 1:
+            out["ms_per_step_by_rank"] = rank_ms          # a straggler shows here; ms_per_step is their maximum
         tb = table.cpu()
-        out["sample_result"] = {"lufs": float(tb[0, 0]), "true_peak_db": float(tb[0, 1]), "tracks_reported": int(tb.shape[0]),
-                                "lufs_min": float(tb[:, 0].min()), "lufs_max": float(tb[:, 0].max()), "true_peak_db_max": float(tb[:, 1].max())}
+        if wl == "stft":
+            out["sample_result"] = {"spectrum_db_max_track0": float(tb[0, 0]), "spectrum_db_mean_track0": float(tb[0, 1]), "tracks_reported": int(tb.shape[0]),
+                                    "frames_per_track": int(nframes), "bins": NFFT // 2}
+        else:
+            out["sample_result"] = {"lufs": float(tb[0, 0]), "true_peak_db": float(tb[0, 1]), "tracks_reported": int(tb.shape[0]),
+                                    "lufs_min": float(tb[:, 0].min()), "lufs_max": float(tb[:, 0].max()), "true_peak_db_max": float(tb[:, 1].max())}
         if chain_like:
             out["sample_result"].update(lufs_in=float(tb[0, 2]), gain_db=float(tb[0, 3]))
         if world == 1 and not args.no_cpu_baseline:

@@ -48,6 +48,14 @@ int wam_trim_workspace(void);
  * -fgpu-rdc): out[2s] = solves, out[2s+1] = iterations; s = 0 follower, 1 follower pair, 2 release smoother. */
 int wam_debug_counters(uint64_t out[8], int reset);
 
+/* Shader clock in MHz under sustained f64 load: every CU runs independent v_fma_f64 chains for about `millis` ms and the shader
+ * clock counter is read against the constant-rate counter.  bench.py prices its VALU roofline with this, not with the nominal 2.4 GHz. */
+int wam_probe_shader_clock(double millis, double* mhz);
+
+/* Host-pointer staging knobs of wam_tune: "stage_pinned" (1: pinned rings + copy threads, csrc/staging.hip; 0: hipMemcpyAsync on
+ * the caller's pageable memory), "stage_threads" (1..8), "host_group" (tracks per staging group of wam_batch_render);
+ * "stft_literal" 0 fastest kernel, 1 the literal loop nest of spectrogram.js, 2 the register-blocked workgroup kernel. */
+
 #ifdef __cplusplus
 }
 #endif

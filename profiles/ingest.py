@@ -10,16 +10,31 @@ cp("bench.json", f"{pre}_chain_T1024_bench.json")
 cp("bench_meter.json", f"{pre}_meter_T1024_bench.json")
 cp("bench_under_rocprof.json", f"{pre}_chain_T1024_bench_under_rocprof.json")
 cp(os.path.join("trace", "trace_kernel_stats.csv"), f"{pre}_chain_T1024_kernel_stats.csv")
+for extra, name in (("bench_stft.json", "stft_T1024"), ("bench_single.json", "chain_single"), ("bench_longform.json", "chain_longform"), ("bench_T128.json", "chain_T128")):
+    if os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 0:
+        cp(extra, f"{pre}_{name}_bench.json")
 NSC = 128 * 2 * 8640000      # sample-channels per launch in the PMC passes (128 tracks)
-out = subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), os.path.join(src, "pmc"), str(NSC)], capture_output=True, text=True, check=True).stdout
-lines = out.splitlines()
-ncol = lines[0].count(",")
-lines.insert(1, "#tracks_per_launch,128" + "," * (ncol - 1))
-open(os.path.join(here, f"{pre}_pmc_summary.csv"), "w").write("\n".join(lines) + "\n")
-msrc = os.path.join(src, "meter", "pmc")
-if os.path.isdir(msrc):       # the meter workload's passes (k_meter, k_gate)
-    out = subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), msrc, str(NSC)], capture_output=True, text=True, check=True).stdout
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+sys.path.insert(0, root)
+import bench  # noqa: E402
+here_digest = bench.source_digest()
+
+
+def summary(pmc_dir, units, out_name):
+    """pmc_summary.py over one directory of passes, plus the meta rows bench.py reads: tracks per launch, the digest of the kernel
+    sources the passes were taken from (written on the GPU box) and the commit whose sources have that digest (HEAD, when they do)."""
+    out = subprocess.run([sys.executable, os.path.join(here, "pmc_summary.py"), pmc_dir, str(units)], capture_output=True, text=True, check=True).stdout
     lines = out.splitlines()
-    lines.insert(1, "#tracks_per_launch,128" + "," * (lines[0].count(",") - 1))
-    open(os.path.join(here, f"{pre}_pmc_meter_summary.csv"), "w").write("\n".join(lines) + "\n")
+    pad = "," * (lines[0].count(",") - 1)
+    dg = open(os.path.join(pmc_dir, "source_digest.txt")).read().strip() if os.path.exists(os.path.join(pmc_dir, "source_digest.txt")) else ""
+    meta = ["#tracks_per_launch,128" + pad, "#source_digest," + dg + pad,
+            "#commit," + (head if dg and dg == here_digest else f"unknown (sources differ from {head})") + pad]
+    open(os.path.join(here, out_name), "w").write("\n".join([lines[0]] + meta + lines[1:]) + "\n")
+
+
+summary(os.path.join(src, "pmc"), NSC, f"{pre}_pmc_summary.csv")
+if os.path.isdir(os.path.join(src, "meter", "pmc")):       # the meter workload's passes (k_meter, k_gate)
+    summary(os.path.join(src, "meter", "pmc"), NSC, f"{pre}_pmc_meter_summary.csv")
+if os.path.isdir(os.path.join(src, "stft", "pmc")):        # the STFT workload's passes; per MONO sample (SURVEY.md 8d: 12 B per mono input sample)
+    summary(os.path.join(src, "stft", "pmc"), NSC // 2, f"{pre}_pmc_stft_summary.csv")
 print("ingested", tag)

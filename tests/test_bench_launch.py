@@ -84,3 +84,49 @@ def test_cpu_all_cores_leg_shape():
     import bench
     r = bench.cpu_all_cores("meter", 48000, 2, 1)
     assert r["kind"] == "port" and r["processes"] >= 1 and r["value"] > 0
+
+
+def test_stuck_rank_is_named_and_the_job_ends_non_zero(tmp_path, capfd, monkeypatch):
+    """A rank that never finishes (stuck in rendezvous or in a collective) must not hold the job until the driver's own limit: after
+    the launcher's timeout - a default exists, WAM_BENCH_TIMEOUT overrides it - the ranks still running are named and killed."""
+    import bench
+    assert bench.LAUNCH_TIMEOUT_S > 0                                              # there IS a default
+    stub = tmp_path / "stub.py"
+    stub.write_text(textwrap.dedent("""
+        import os, time
+        if os.environ["RANK"] == "0":
+            raise SystemExit(0)
+        time.sleep(600)
+    """))
+    monkeypatch.setenv("WAM_BENCH_TIMEOUT", "3")
+    t0 = time.time()
+    rc = bench.launch_ranks(3, [], script=str(stub))                               # no explicit timeout: the default path
+    err = capfd.readouterr().err
+    assert rc == 124 and time.time() - t0 < 30
+    assert "rank(s) [1, 2] still running after 3 s" in err
+
+
+def test_per_rank_step_times_are_gathered_in_rank_order():
+    """The N > 1 bench line carries every rank's own ms_per_step (a straggler is visible; the headline is their maximum): the
+    gathering is wam_dist.gather_track_scalars with one row per rank - checked here over gloo with three ranks."""
+    code = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, os.path.join(%r, "web-audio-mastering_amd", "python"))
+        import torch, torch.distributed as dist, wam_dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ms = 100.0 + 7 * rank
+        got = wam_dist.gather_track_scalars(torch.tensor([[ms]], dtype=torch.float64), world, "cpu")[:, 0].tolist()
+        worst = wam_dist.max_over_ranks(ms, "cpu")
+        if rank == 0:
+            print(json.dumps({"by_rank": got, "max": worst}))
+        dist.destroy_process_group()
+    """ % ROOT)
+    import bench
+    port = bench.free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=clean_env(RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert r["by_rank"] == [100.0, 107.0, 114.0] and r["max"] == 114.0

@@ -92,3 +92,52 @@ extern "C" int wam_synth_dev(float* out_dev, int ntracks, int nch, int64_t n, do
   WAM_LAUNCH("k_synth", k_synth, dim3((unsigned)bx, (unsigned)(ntracks * nch)), dim3(256), (hipStream_t)stream, out_dev, nch, n, idx0, a);
   return WAM_OK;
 }
+
+// ---- shader clock under f64 load (bench.py: the peak of its VALU roofline is derived from the clock the chip really runs at) ----
+namespace wam {
+// Every lane runs eight independent chains of v_fma_f64 (the chain kernels' instruction mix) for `iters` rounds; lane 0 of each
+// workgroup reports shader-clock ticks (s_memtime) and constant-rate ticks (s_memrealtime) across its loop.
+__global__ __launch_bounds__(256) void k_clock_probe(int64_t iters, unsigned long long* __restrict__ ticks, double* __restrict__ sink) {
+  double a0 = 1e-9 * threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const double m = 0.999999999, c = 1e-12;
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  for (int64_t i = 0; i < iters; i++) {
+    a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+    a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+  const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  if (s == 12345.678) sink[0] = s;                       // keeps the chains alive
+}
+}  // namespace wam
+
+// Runs the probe for about `millis` ms on every CU (2 workgroups of 4 wavefronts per CU: the chain kernels' occupancy) and returns
+// the shader clock in MHz it saw: (shader ticks / constant-rate ticks) x the constant rate the device reports.
+extern "C" int wam_probe_shader_clock(double millis, double* mhz) {
+  using namespace wam;
+  if (!mhz || !(millis > 0)) { set_error("invalid probe arguments"); return WAM_ERR_INVALID; }
+  int rc = ensure_device(); if (rc) return rc;
+  int dev = 0, cus = 0, wall_khz = 0;
+  WAM_HIP(hipGetDevice(&dev));
+  WAM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  WAM_HIP(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev));
+  if (cus <= 0 || wall_khz <= 0) { set_error("device reports no CU count / wall clock rate"); return WAM_ERR_HIP; }
+  const int blocks = 2 * cus;
+  DevBuf tb, sk;
+  rc = tb.alloc(sizeof(unsigned long long) * 2 * blocks); if (rc) return rc;
+  rc = sk.alloc(sizeof(double)); if (rc) return rc;
+  // a wavefront issues one v_fma_f64 per ~4 cycles per chain slot; 2 wavefronts share a SIMD: 8 FMAs per round ~ 64 cycles
+  const int64_t iters = (int64_t)(millis * 1e-3 * 2.0e9 / 64.0) + 1;
+  std::vector<unsigned long long> h(2 * (size_t)blocks);
+  for (int pass = 0; pass < 2; pass++) {                  // the first pass brings the clock up
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, nullptr, iters, tb.as<unsigned long long>(), sk.as<double>());
+    WAM_HIP(hipGetLastError());
+    WAM_HIP(hipMemcpy(h.data(), tb.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+  }
+  double st = 0, wt = 0;
+  for (int b = 0; b < blocks; b++) { st += (double)h[2 * b]; wt += (double)h[2 * b + 1]; }
+  if (!(wt > 0)) { set_error("clock probe returned no ticks"); return WAM_ERR_HIP; }
+  *mhz = st / wt * (double)wall_khz / 1e3;
+  return WAM_OK;
+}
