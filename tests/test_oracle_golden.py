@@ -50,6 +50,7 @@ def test_meter(golden, name):
     if "block_ms" in c:
         assert np.array_equal(blocks, G.f64(c["block_ms"]))
         assert np.array_equal(mask, G.u8(c["gate_mask"]))
+    assert G.gate_margin(blocks) > 1e-12                 # no block within 1e-12 (relative) of a gate: the masks are robust to the summation order
     for ch, dc in zip(x, c["dc"]):
         assert O.dc_detect(ch) == G.num(dc) or (np.isnan(G.num(dc)))
 
@@ -62,6 +63,7 @@ def test_meter_180s(golden):
     close(O.true_peak_db(x), G.num(c["tp_db"]))
     assert len(blocks) == c["nblocks"] == 1797
     assert int((mask >= 1).sum()) == c["ngate_abs"] and int((mask == 2).sum()) == c["ngate_rel"]
+    assert G.gate_margin(blocks) > 1e-12
 
 
 def test_short_term_momentary(golden):

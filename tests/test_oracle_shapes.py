@@ -34,6 +34,7 @@ def test_meter_shapes(name):
     assert len(blocks) == c["nblocks"]
     assert np.array_equal(blocks, G.f64(c["block_ms"]))
     assert np.array_equal(mask, G.u8(c["gate_mask"]))
+    assert G.gate_margin(blocks) > 1e-12                 # (tests/golden_util.py: the GPU gate sums in tree order)
     for pos, v in c["short_term"]:
         close(O.short_term_lufs(x, c["sr"], pos), G.num(v))
     for pos, v in c["momentary"]:

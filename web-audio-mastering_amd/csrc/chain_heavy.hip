@@ -121,27 +121,69 @@ __global__ __launch_bounds__(kThreads) void k_win_peak(const float* __restrict__
   }
 }
 
-__global__ void k_warm_env(const unsigned* __restrict__ winpeak, int ntracks, int64_t nw, double thr, double kst, int64_t lw,
-                           float* __restrict__ sm, float* __restrict__ env) {
-  const int64_t trk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (trk >= ntracks) return;
+// One wavefront per track.  The smoothing (multiband-saturation.js:243-253) is a chain of f32 STORES - every step rounds - so it
+// is walked in order, by lane 0; what the lanes share is everything around the chain: the window peaks arrive 2,048 at a time
+// in coalesced loads, the soft-knee value of each window (:232-241) is computed by all lanes, and the chain itself reads and
+// writes LDS four values per access.  (Round 2: one thread per track doing all of it, 36,000 dependent global loads on the
+// 60-minute track: 8.1 ms; now the chain's own ~35 cycles per window.)
+constexpr int kWarmEnvChunk = 2048;
+__global__ __launch_bounds__(64) void k_warm_env(const unsigned* __restrict__ winpeak, int ntracks, int64_t nw, double thr, double kst,
+                                                  float* __restrict__ sm) {
+#pragma clang fp contract(off)       // smoothed[i - 1] + (envelope[i] - smoothed[i - 1]) * coef: the product is rounded before the sum, as in JavaScript
+  __shared__ __align__(16) float ev_s[kWarmEnvChunk];
+  __shared__ __align__(16) float sm_s[kWarmEnvChunk];
+  const int64_t trk = blockIdx.x;
+  const int lane = threadIdx.x;
   const unsigned* wp = winpeak + trk * nw;
   float* s = sm + trk * nw;
-  float* e = env + trk * nw;
   float prev = 0;
-  for (int64_t w = 0; w < nw; w++) {
-    const double peak = (double)__uint_as_float(wp[w]);
-    float ev;
-    if (peak >= thr) ev = 1.0f;
-    else if (peak >= kst) { const double r = (peak - kst) / (thr - kst); ev = f32r(r * r); }
-    else ev = 0.0f;
-    if (w == 0) prev = ev;
-    else { const double coef = ev > prev ? 0.5 : 0.03; prev = f32r((double)prev + ((double)ev - (double)prev) * coef); }
-    s[w] = prev;
+  for (int64_t c0 = 0; c0 < nw; c0 += kWarmEnvChunk) {
+    const int m = (int)(nw - c0 < kWarmEnvChunk ? nw - c0 : kWarmEnvChunk);
+    for (int i = lane; i < m; i += 64) {
+      const double peak = (double)__uint_as_float(wp[c0 + i]);
+      float ev;
+      if (peak >= thr) ev = 1.0f;
+      else if (peak >= kst) { const double r = (peak - kst) / (thr - kst); ev = f32r(r * r); }
+      else ev = 0.0f;
+      ev_s[i] = ev;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int i = 0;
+      if (c0 == 0) { prev = ev_s[0]; sm_s[0] = prev; i = 1; }           // smoothed[0] = envelope[0]
+      for (; i < m && (i & 3); i++) {
+        const float ev = ev_s[i];
+        const double coef = ev > prev ? 0.5 : 0.03;
+        prev = f32r((double)prev + ((double)ev - (double)prev) * coef);
+        sm_s[i] = prev;
+      }
+      for (; i + 4 <= m; i += 4) {
+        const float4 e4 = *reinterpret_cast<const float4*>(&ev_s[i]);
+        float4 o;
+        { const double c = e4.x > prev ? 0.5 : 0.03; prev = f32r((double)prev + ((double)e4.x - (double)prev) * c); o.x = prev; }
+        { const double c = e4.y > prev ? 0.5 : 0.03; prev = f32r((double)prev + ((double)e4.y - (double)prev) * c); o.y = prev; }
+        { const double c = e4.z > prev ? 0.5 : 0.03; prev = f32r((double)prev + ((double)e4.z - (double)prev) * c); o.z = prev; }
+        { const double c = e4.w > prev ? 0.5 : 0.03; prev = f32r((double)prev + ((double)e4.w - (double)prev) * c); o.w = prev; }
+        *reinterpret_cast<float4*>(&sm_s[i]) = o;
+      }
+      for (; i < m; i++) {
+        const float ev = ev_s[i];
+        const double coef = ev > prev ? 0.5 : 0.03;
+        prev = f32r((double)prev + ((double)ev - (double)prev) * coef);
+        sm_s[i] = prev;
+      }
+    }
+    __syncthreads();
+    for (int i = lane; i < m; i += 64) s[c0 + i] = sm_s[i];
+    __syncthreads();
   }
-  for (int64_t w = 0; w < nw; w++) {
-    int64_t f = w + lw; if (f > nw - 1) f = nw - 1;
-    e[w] = lw > 0 ? s[f] : s[w];
+}
+// the look-ahead shift (:255-268): envelope[w] = smoothed[min(w + lookaheadWindows, numWindows - 1)]
+__global__ void k_warm_env_shift(const float* __restrict__ sm, int ntracks, int64_t nw, int64_t lw, float* __restrict__ env) {
+  const int64_t trk = blockIdx.y;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f = w + (lw > 0 ? lw : 0); if (f > nw - 1) f = nw - 1;
+    env[trk * nw + w] = sm[trk * nw + f];
   }
 }
 
@@ -382,8 +424,9 @@ int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const Hea
   int64_t bx = nw < 512 ? nw : 512;
   WAM_LAUNCH("k_win_peak", k_win_peak, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, nch, n, ws, nw, winpeak, pre_gain);
   const double thr = std::pow(10, -24 / 20.0), kst = std::pow(10, (-24 - 6) / 20.0);          // multiband-saturation.js:210-211, preset :35
-  WAM_LAUNCH("k_warm_env", k_warm_env, dim3((unsigned)((ntracks + 63) / 64)), dim3(64), s, (const unsigned*)winpeak, ntracks, nw, thr, kst,
-             hp_host.w_lw, sm, env);
+  WAM_LAUNCH("k_warm_env", k_warm_env, dim3((unsigned)ntracks), dim3(64), s, (const unsigned*)winpeak, ntracks, nw, thr, kst, sm);
+  int64_t sx = (nw + 255) / 256; if (sx > 256) sx = 256;
+  WAM_LAUNCH("k_warm_env", k_warm_env_shift, dim3((unsigned)sx, (unsigned)ntracks), dim3(256), s, (const float*)sm, ntracks, nw, hp_host.w_lw, env);
   return WAM_OK;
 }
 

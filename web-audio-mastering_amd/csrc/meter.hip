@@ -148,17 +148,16 @@ __global__ void k_norm_gain(const GateOut* __restrict__ gate, const MeterPlan* _
   gains[t] = isfinite(lufs) ? pow(10.0, (target - lufs) / 20) : 1.0;
 }
 
-// Gating (lufs.js:57-81).  blocks: scratch [ntracks][nblocks] (always written).
-__global__ __launch_bounds__(256) void k_gate(const double* __restrict__ hopsums, int64_t hop_stride, const double* __restrict__ peaks,
-                                              const MeterPlan* __restrict__ plan, double* __restrict__ blocks, uint8_t* __restrict__ mask,
-                                              GateOut* __restrict__ out) {
+// 400 ms block energies from the hop sums (lufs.js:57-66), every block on its own: blocks [ntracks][nblocks] (always written).
+__global__ __launch_bounds__(256) void k_gate_blocks(const double* __restrict__ hopsums, int64_t hop_stride, const MeterPlan* __restrict__ plan,
+                                                     double* __restrict__ blocks) {
   const MeterPlan& pl = *plan;
-  const int64_t trk = blockIdx.x;
+  const int64_t trk = blockIdx.y;
   const int nch = pl.nch;
   const int64_t nb = pl.nblocks;
   double* bl = blocks + trk * (nb > 0 ? nb : 1);
   const double denom = (double)(pl.block * nch);
-  for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (int64_t)gridDim.x * blockDim.x) {
     double ss = 0;
     for (int c = 0; c < nch; c++) {
       const double* hs = hopsums + (trk * nch + c) * hop_stride;
@@ -168,33 +167,52 @@ __global__ __launch_bounds__(256) void k_gate(const double* __restrict__ hopsums
     }
     bl[b] = ss / denom;
   }
-  __syncthreads();
-  __shared__ double stage[2048];
-  __shared__ double s_mean1;
-  double s1 = 0, s2 = 0;
-  int64_t c1 = 0, c2 = 0;
-  // pass 1: absolute gate, sequential sum in block order
-  for (int64_t b0 = 0; b0 < nb; b0 += 2048) {
-    const int64_t m = nb - b0 < 2048 ? nb - b0 : 2048;
-    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) stage[i] = bl[b0 + i];
-    __syncthreads();
-    if (threadIdx.x == 0) for (int64_t i = 0; i < m; i++) { const double v = stage[i]; if (v > 1e-7) { s1 += v; c1++; } }
-    __syncthreads();
+}
+
+// Gating (lufs.js:67-81), one workgroup per track: two block reductions (the north star's "two-pass block reduction").  The
+// reference adds the surviving block energies in block order; here thread t adds blocks t, t + 256, ... in order and the 256
+// partial sums are combined in a fixed tree, so the result is deterministic (the same for any launch shape) and differs from
+// the sequential sum by a few units of 1e-16 - which could move a block across the relative gate only if its energy sat within
+// ~1e-15 of 0.1 x mean; tests/test_oracle_golden.py asserts a margin of 1e-12 on every fixture, the gate masks are compared with
+// the reference's one by one, and LUFS agrees to 1e-9 LU.  (Rounds 1-2 walked the blocks with one lane: exact in order, but
+// ~80 cycles per block on a single lane - 3.8 ms for the 36,000 blocks of the 60-minute track.)
+__device__ __forceinline__ void gate_reduce(double& s, long long& c, double* lds_s, long long* lds_c) {
+  // wavefront: fixed butterfly order; then the four wave sums in order
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double so = __shfl_xor(s, d); const long long co = __shfl_xor(c, d);
+    const bool low = (lane_id() & d) == 0;
+    s = low ? s + so : so + s;                       // both partners form (lower lane's value) + (upper lane's value): identical results
+    c += co;
   }
-  if (threadIdx.x == 0) s_mean1 = c1 > 0 ? s1 / (double)c1 : 0.0;
   __syncthreads();
-  const double thr = s_mean1 * 0.1;
-  for (int64_t b0 = 0; b0 < nb; b0 += 2048) {
-    const int64_t m = nb - b0 < 2048 ? nb - b0 : 2048;
-    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
-      const double v = bl[b0 + i];
-      stage[i] = v;
-      if (mask) mask[trk * (nb > 0 ? nb : 1) + b0 + i] = (v > 1e-7) ? ((v > thr) ? 2 : 1) : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) for (int64_t i = 0; i < m; i++) { const double v = stage[i]; if (v > 1e-7 && v > thr) { s2 += v; c2++; } }
-    __syncthreads();
+  if (lane_id() == 0) { lds_s[wave_id()] = s; lds_c[wave_id()] = c; }
+  __syncthreads();
+  s = ((lds_s[0] + lds_s[1]) + lds_s[2]) + lds_s[3];
+  c = ((lds_c[0] + lds_c[1]) + lds_c[2]) + lds_c[3];
+}
+__global__ __launch_bounds__(256) void k_gate(const double* __restrict__ peaks, const MeterPlan* __restrict__ plan, const double* __restrict__ blocks,
+                                              uint8_t* __restrict__ mask, GateOut* __restrict__ out) {
+  const MeterPlan& pl = *plan;
+  const int64_t trk = blockIdx.x;
+  const int nch = pl.nch;
+  const int64_t nb = pl.nblocks;
+  const double* bl = blocks + trk * (nb > 0 ? nb : 1);
+  __shared__ double lds_s[4];
+  __shared__ long long lds_c[4];
+  double s1 = 0; long long c1 = 0;
+  for (int64_t b = threadIdx.x; b < nb; b += 256) { const double v = bl[b]; const bool keep = v > 1e-7; s1 += keep ? v : 0.0; c1 += keep ? 1 : 0; }
+  gate_reduce(s1, c1, lds_s, lds_c);
+  const double mean1 = c1 > 0 ? s1 / (double)c1 : 0.0;
+  const double thr = mean1 * 0.1;
+  double s2 = 0; long long c2 = 0;
+  for (int64_t b = threadIdx.x; b < nb; b += 256) {
+    const double v = bl[b];
+    const bool keep = v > 1e-7 && v > thr;
+    s2 += keep ? v : 0.0; c2 += keep ? 1 : 0;
+    if (mask) mask[trk * (nb > 0 ? nb : 1) + b] = (v > 1e-7) ? ((v > thr) ? 2 : 1) : 0;
   }
+  gate_reduce(s2, c2, lds_s, lds_c);
   if (threadIdx.x == 0) {
     GateOut o;
     o.c1 = c1; o.c2 = c2; o.nblocks = nb;
@@ -267,7 +285,11 @@ void carve_meter_scratch(const MeterPlan& pl, int ntracks, bool want_mask, void*
 }
 
 int enqueue_gate(const MeterPlan& pl, int ntracks, const MeterScratch& s, hipStream_t stream) {
-  WAM_LAUNCH("k_gate", k_gate, dim3(ntracks), dim3(256), stream, s.hopsums, s.hop_stride, s.peaks, s.plan, s.blocks, s.mask, s.gate);
+  {
+    int64_t bx = (pl.nblocks + 255) / 256; if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
+    WAM_LAUNCH("k_gate", k_gate_blocks, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), stream, (const double*)s.hopsums, s.hop_stride, (const MeterPlan*)s.plan, s.blocks);
+  }
+  WAM_LAUNCH("k_gate", k_gate, dim3(ntracks), dim3(256), stream, (const double*)s.peaks, (const MeterPlan*)s.plan, (const double*)s.blocks, s.mask, s.gate);
   return WAM_OK;
 }
 
