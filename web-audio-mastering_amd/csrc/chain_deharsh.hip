@@ -7,7 +7,8 @@
 // round to f32 wherever the reference stores into a Float32Array:
 //   k_dh_bands_x: every frame in parallel -> windowed FFT -> the frame's 1,024 f32 magnitudes into a scratch array
 //   k_dh_bandsum: one LANE per frame walks its magnitudes bin by bin: the reference's sequential f32 band sums -> 7 band RMS values
-//   k_dh_follow : per (channel, band) the per-frame envelope follower + soft-knee gain  (serial over frames, tiny)
+//   k_dh_follow : per (channel, band) the per-frame envelope follower (serial over frames, tiny)
+//   k_dh_gain   : the soft-knee gain of every envelope value
 //   k_dh_apply_x: one wavefront per (channel, segment of frames) walks its frames in order: FFT, per-bin resonance EMA and
 //                 overlap-add ring in registers, gains, inverse FFT, synthesis window, dry/wet mix (<true>: presets other than
 //                 'mastering', their parameters from the plan).
@@ -301,35 +302,52 @@ __device__ __forceinline__ float band_gain_db_of(double env, const DeharshPlan& 
   return f32r(gdb);
 }
 
-// Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43) and the soft-knee gain of its
-// envelope.  band_gdb: [chan][frame][7] float (the reference keeps the gains in a Float32Array).  The release coefficient is per SAMPLE but the follower is stepped per frame, so its memory spans the whole
-// track (no warm-up segmentation); instead one workgroup per (channel, band) walks the frames in tiles of 4,096 with
-// the same policy-iteration scan as the per-sample followers (an hour at 96 kHz is 337 k frames = 83 tiles).
+// Per (channel, band): the envelope follower over frames (EnvelopeFollower.process, :33-43).  The release coefficient is per
+// SAMPLE but the follower is stepped per frame, so its memory spans the whole track (no warm-up segmentation); instead one
+// workgroup per (channel, band) walks the frames in tiles of 4,096 with the same policy-iteration scan as the per-sample
+// followers (an hour at 96 kHz is 337 k frames = 83 tiles).  The walk is the only serial part, so nothing else is on it: the
+// next tile's levels are loaded before this tile is solved, and the envelope leaves as doubles - its soft-knee gain (a log10
+// per frame and band) is k_dh_gain's, over the whole grid.  env: [chan][frame][7] double.
 __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict__ band_rms, const DeharshPlan* __restrict__ dp, int nchan,
-                                                        float* __restrict__ band_gdb) {
+                                                        double* __restrict__ env) {
   __shared__ double lds_scan[kSlotDoubles];
   const DeharshPlan& P = *dp;
   const int chan = blockIdx.x / kBands, b = blockIdx.x % kBands;
   const double A = P.A[b], R = P.R[b];
   const int64_t F = P.nframes;
   const float* src = band_rms + (int64_t)chan * F * kBands + b;
-  float* dst = band_gdb + (int64_t)chan * F * kBands + b;
+  double* dst = env + (int64_t)chan * F * kBands + b;
   LdsSlots slots(lds_scan);
   double Senv = 0;
   const int64_t ntiles = (F + kTile - 1) / kTile;
+  float nx[C];
+  // frames past the end: a = 0 keeps the recurrence defined; nothing is stored for them
+  auto fetch = [&](int64_t t) {
+    const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
+#pragma unroll
+    for (int k = 0; k < C; k++) nx[k] = (base + k < F) ? fabsf(src[(base + k) * kBands]) : 0.0f;
+  };
+  fetch(0);
   for (int64_t t = 0; t < ntiles; t++) {
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     float a[C];
 #pragma unroll
-    for (int k = 0; k < C; k++) a[k] = (base + k < F) ? fabsf(src[(base + k) * kBands]) : 0.0f;
-    // frames past the end: a = 0 keeps the recurrence defined; nothing is stored for them
+    for (int k = 0; k < C; k++) a[k] = nx[k];
+    if (t + 1 < ntiles) fetch(t + 1);
     double e = follower_solve(a, A, R, Senv, slots.next());
 #pragma unroll
     for (int k = 0; k < C; k++) {
       e = follower_step(e, (double)a[k], A, R);
-      if (base + k < F) dst[(base + k) * kBands] = band_gain_db_of(e, P, b);
+      if (base + k < F) dst[(base + k) * kBands] = e;
     }
   }
+}
+// the soft-knee gain of every envelope value.  band_gdb: [chan][frame][7] float (the reference keeps the gains in a Float32Array)
+__global__ __launch_bounds__(256) void k_dh_gain(const double* __restrict__ env, const DeharshPlan* __restrict__ dp, int64_t total,
+                                                 float* __restrict__ band_gdb) {
+  const DeharshPlan& P = *dp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    band_gdb[i] = band_gain_db_of(env[i], P, (int)(i % kBands));
 }
 
 // Synthesis.  Every WAVEFRONT owns one segment [f0, f1) of one channel's frames and emits the samples [f0 * 512, f1 * 512)
@@ -1020,6 +1038,8 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   rc = winb.alloc(sizeof(float) * kN); if (rc) return rc;
   rc = rms.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
   rc = gdb.alloc(sizeof(float) * nf * kBands * nchan); if (rc) return rc;
+  DevBuf envd;
+  rc = envd.alloc(sizeof(double) * nf * kBands * nchan); if (rc) return rc;
   std::vector<float2> tw(kTw1 + kTwB);
   std::vector<float> win(kN);
   for (int k = 0; k < kTw1; k++) { const double a = -2 * M_PI * k / kM; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
@@ -1064,7 +1084,10 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
     else WAM_LAUNCH("k_dh_bands", k_dh_bands, dim3((unsigned)gx, (unsigned)nchan), dim3(256), s, in, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                winb.as<float>(), rms.as<float>(), pre_gain);
     WAM_LAUNCH("k_dh_follow", k_dh_follow, dim3((unsigned)(nchan * kBands)), dim3(kThreads), s, (const float*)rms.as<float>(),
-               plan.as<DeharshPlan>(), nchan, gdb.as<float>());
+               plan.as<DeharshPlan>(), nchan, envd.as<double>());
+    const int64_t total = (int64_t)dp.nframes * kBands * nchan;
+    int64_t gg = (total + 255) / 256; if (gg > 16384) gg = 16384;
+    WAM_LAUNCH("k_dh_gain", k_dh_gain, dim3((unsigned)gg), dim3(256), s, (const double*)envd.as<double>(), plan.as<DeharshPlan>(), total, gdb.as<float>());
   }
   // segments are walked by wavefronts, four to a workgroup: aim at ~16 k wavefronts (12 are resident per CU)
   // exact mode: the resonance EMA (an f32 state) must forget its start far below one f32 rounding, not to ~1e-7:
