@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_dh_bands(const float* __restrict__ in, 
 #pragma unroll
   for (int b = 0; b < 8; b++) ba[b * 64 + lane] = 0.0f;
   WaveTw T; load_wave_tw(twg, T, tws);
-  __syncthreads();
+  lds_barrier();
   const int ob = wave_out_base();
   uint64_t bands = 0;                           // 3 bits per bin: bins k = lane + 64 j at 3 j, bins 1024 - k at 24 + 3 j
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply(const float* __restrict__ i
   const float* win = wing;                       // read through L1: coalesced, the same 8 KB for every frame
   WaveTw T; load_wave_tw(twg, T, tws);
   for (int i = threadIdx.x; i < kM / 2; i += 256) twBs[i] = twg[kTw1 + i];
-  __syncthreads();
+  lds_barrier();
   const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
   if (seg >= nseg) return;                       // no workgroup barrier below
   auto load_in = [&](int64_t s) -> float {
@@ -572,10 +572,13 @@ constexpr int kTwsLds = kTwq + kTwlLds * 64;                       // dcx entrie
 // The analysis / synthesis window.  The f32 Hann table is symmetric (win[i] == win[2047 - i], checked on the host when the
 // table is built), so its first half fits the LDS beside the twiddles: 512 float2; otherwise the kernels read the full
 // table from global memory.
-struct WinSrc { const float* g; const float2* h; int sym; };
-template <bool LOW>                                                // LOW: m < 512 known at compile time
-__device__ __forceinline__ float2 window_pair(const WinSrc& W, int m) {   // (win[2 m], win[2 m + 1])
-  if (!W.sym) return ((const float2*)W.g)[m];
+// SYM (the table mirrors in f32: its first half is in LDS) is a template parameter, not a flag: with a run-time flag the compiler
+// turns `sym ? LDS : global` into a select of generic pointers and every window read into a FLAT load, which counts on vmcnt and
+// lgkmcnt alike and so makes the frame wait for the next frame's samples that are meant to stay in flight.
+template <bool SYM> struct WinSrc { const float* g; const float2* h; };
+template <bool LOW, bool SYM>                                      // LOW: m < 512 known at compile time
+__device__ __forceinline__ float2 window_pair(const WinSrc<SYM>& W, int m) {   // (win[2 m], win[2 m + 1])
+  if constexpr (!SYM) return ((const float2*)W.g)[m];
   if (LOW) return W.h[m];
   const float2 t = W.h[kM - 1 - m];
   return make_float2(t.y, t.x);
@@ -583,7 +586,7 @@ __device__ __forceinline__ float2 window_pair(const WinSrc& W, int m) {   // (wi
 __device__ __forceinline__ void load_tables_lds(dcx* tws, float2* winh, const dcx* __restrict__ twd, const float* __restrict__ wing) {
   for (int i = threadIdx.x; i < kTwsLds; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
   for (int i = threadIdx.x; i < kM / 2; i += 256) winh[i] = ((const float2*)wing)[i];
-  __syncthreads();
+  lds_barrier();
 }
 template <bool INV>
 __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD& T) {
@@ -655,7 +658,8 @@ __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
 // the windowed frame is a Float32Array in the reference (fft.js:30,44): the f32 product IS that store (exact product, one rounding)
 // (split from the loads: the kernels issue a frame's loads while the previous frame is still being finished - load_frame_raw -
 // and window it here when its turn comes)
-__device__ __forceinline__ void window_frame_d(const float2 vf[16], const WinSrc& W, double pre_gain, dcx v[16]) {
+template <bool SYM>
+__device__ __forceinline__ void window_frame_d(const float2 vf[16], const WinSrc<SYM>& W, double pre_gain, dcx v[16]) {
   const int lane = lane_id();
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -663,7 +667,7 @@ __device__ __forceinline__ void window_frame_d(const float2 vf[16], const WinSrc
     if (pre_gain != 1.0) { v0 = f32r((double)v0 * pre_gain); v1 = f32r((double)v1 * pre_gain); }
     if (!(v0 == v0)) v0 = 0.0f;                                    // (input[i] || 0)
     if (!(v1 == v1)) v1 = 0.0f;
-    const float2 w = r < 8 ? window_pair<true>(W, 64 * r + lane) : window_pair<false>(W, 64 * r + lane);
+    const float2 w = r < 8 ? window_pair<true, SYM>(W, 64 * r + lane) : window_pair<false, SYM>(W, 64 * r + lane);
     v[r] = dcx{ (double)(v0 * w.x), (double)(v1 * w.y) };
   }
 }
@@ -745,9 +749,10 @@ __global__ __launch_bounds__(256) void k_dh_bandsum(const float* __restrict__ ma
 #undef WAM_SUM_NEXT
 }
 
+template <bool SYM>
 __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__ in, int64_t n, const DeharshPlan* __restrict__ dp,
                                                        const dcx* __restrict__ twd, const float* __restrict__ wing,
-                                                       float* __restrict__ mags_out, double pre_gain, int win_sym) {
+                                                       float* __restrict__ mags_out, double pre_gain) {
   __shared__ dcx buf[4][kWaveBuf];
   __shared__ dcx tws[kTwsLds];
   __shared__ float2 winh[kM / 2];
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
     const WaveTwD T{ tws + toff + kTwq, tws + toff };
     const dcx wl = twf[kTwl + kTwq + lane];                        // W2048^lane
-    const WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
+    const WinSrc<SYM> Wn{ reload_each_tile(wing), winh + toff };
     window_frame_d(vf, Wn, pre_gain, v);
     {
       const int64_t fn = f + 4 * (int64_t)gridDim.x;                // this wavefront's next frame
@@ -800,11 +805,11 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
 
 // GEN = false: the 'mastering' preset of the export chain, its constants folded.  GEN = true: max cut, sensitivity, the AI-artifact
 // range and the dry/wet mix come from the plan ('gentle', 'aggressive': fully wet, so there is no mix step at all, :419).
-template <bool GEN>
+template <bool GEN, bool SYM>
 __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__ in, float* __restrict__ out, int64_t n,
                                                        const DeharshPlan* __restrict__ dp, const dcx* __restrict__ twd,
                                                        const float* __restrict__ wing, const float* __restrict__ band_gdb, double pre_gain,
-                                                       int64_t seg_frames, int64_t nseg, int64_t warm, int win_sym) {
+                                                       int64_t seg_frames, int64_t nseg, int64_t warm) {
   __shared__ dcx buf[4][kWaveBuf];
   __shared__ dcx tws[kTwsLds];
   __shared__ float2 winh[kM / 2];
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
     WaveTwD T{ tws + toff + kTwq, tws + toff };
 
-    WinSrc Wn{ reload_each_tile(wing), winh + toff, win_sym };
+    WinSrc<SYM> Wn{ reload_each_tile(wing), winh + toff };
     {                                                              // (loads a frame ahead cost this kernel 32 registers it does not have)
       float2 vf[16];
       load_frame_raw(x, f * kHop, vf);
@@ -939,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     asm volatile("" : "+s"(toff));
     T = WaveTwD{ tws + toff + kTwq, tws + toff };
     fft1024_wave_d<true>(v, zw, T);
-    Wn = WinSrc{ reload_each_tile(wing), winh + toff, win_sym };
+    Wn = WinSrc<SYM>{ reload_each_tile(wing), winh + toff };
     wave_sync();                                                   // the exchange's reads precede the float writes below (other layout)
     float2* yf = (float2*)zw;
 #pragma unroll
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       const int m = wave_out_index_d(ob, j);
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
       // m = ob + 16 (j & 3) + 256 (j >> 2) with ob + 16 (j & 3) < 256: the half of the table is known from j alone
-      const float2 ws = j < 8 ? window_pair<true>(Wn, m) : window_pair<false>(Wn, m);   // the inverse's 1 / N is an exact scaling: applied to the window
+      const float2 ws = j < 8 ? window_pair<true, SYM>(Wn, m) : window_pair<false, SYM>(Wn, m);   // the inverse's 1 / N is an exact scaling: applied to the window
       yf[m] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
     }
     wave_sync();
@@ -1074,8 +1079,10 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
       for (int64_t c0 = 0; c0 < nchan; c0 += sub) {
         const int64_t nc = nchan - c0 < sub ? nchan - c0 : sub;
         int64_t gxx = 8192 / nc; if (gxx < 1) gxx = 1; if (gxx > ngroups) gxx = ngroups;
-        WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x, dim3((unsigned)gxx, (unsigned)nc), dim3(256), s, in + c0 * n, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
-                   winb.as<float>(), mags.as<float>(), pre_gain, win_sym);
+        if (win_sym) WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x<true>, dim3((unsigned)gxx, (unsigned)nc), dim3(256), s, in + c0 * n, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
+                   winb.as<float>(), mags.as<float>(), pre_gain);
+        else WAM_LAUNCH("k_dh_bands_x", k_dh_bands_x<false>, dim3((unsigned)gxx, (unsigned)nc), dim3(256), s, in + c0 * n, n, plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(),
+                   winb.as<float>(), mags.as<float>(), pre_gain);
         WAM_LAUNCH("k_dh_bandsum", k_dh_bandsum, dim3((unsigned)((dp.nframes + 255) / 256), (unsigned)nc), dim3(256), s, (const float*)mags.as<float>(),
                    plan.as<DeharshPlan>(), rms.as<float>() + c0 * dp.nframes * kBands);
       }
@@ -1095,10 +1102,11 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   const int64_t warm = exact && tuning().dh_warm_frames < 96 ? 96 : tuning().dh_warm_frames;
   const int64_t seg = pick_segment_tiles(nchan, dp.nframes, warm, tuning().dh_seg_frames, exact ? 8192 : 16384, 2048);
   const int64_t nseg = dp.nframes > 0 ? (dp.nframes + seg - 1) / seg : 1;
-  if (exact && mastering) WAM_LAUNCH("k_dh_apply_x", k_dh_apply_x<false>, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
-                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm, win_sym);
-  else if (exact) WAM_LAUNCH("k_dh_apply_xg", k_dh_apply_x<true>, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(),
-                        (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm, win_sym);
+#define WAM_DH_APPLY_X(name, GEN, SYM) WAM_LAUNCH(name, (k_dh_apply_x<GEN, SYM>), dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, \
+    plan.as<DeharshPlan>(), (const dcx*)twd.as<dcx>(), winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm)
+  if (exact && mastering) { if (win_sym) WAM_DH_APPLY_X("k_dh_apply_x", false, true); else WAM_DH_APPLY_X("k_dh_apply_x", false, false); }
+  else if (exact) { if (win_sym) WAM_DH_APPLY_X("k_dh_apply_xg", true, true); else WAM_DH_APPLY_X("k_dh_apply_xg", true, false); }
+#undef WAM_DH_APPLY_X
   else WAM_LAUNCH("k_dh_apply", k_dh_apply, dim3((unsigned)((nseg + 3) / 4), (unsigned)nchan), dim3(256), s, in, out, n, plan.as<DeharshPlan>(), twb.as<float2>(),
                   winb.as<float>(), (const float*)gdb.as<float>(), pre_gain, seg, nseg, warm);
   WAM_HIP(hipStreamSynchronize(s));           // the scratch above is released on return

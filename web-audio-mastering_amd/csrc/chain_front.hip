@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
   if (threadIdx.x <= NCH) Scar[threadIdx.x] = 0;
   MeterStateL ms[NCH];
   if (do_meter) for (int c = 0; c < NCH; c++) meter_init_l(ms[c], *mp, sg.Tw * kTile, sg, &Pl[kFShelf][0][0], &Pl[kFKhp][0][0], Sl[c * 9 + 7], Sl[c * 9 + 8]);
-  __syncthreads();
+  lds_barrier();
 
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const FrontPlan& P = *reload_each_tile(fp);
@@ -90,10 +90,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         // applyOnePoleLP (final-filters.js:68-78): y starts at data[0]
         if (t == 0) {
           if (threadIdx.x == 0) { bc[0] = f32r(da[0]); bc[1] = f32r(db[0]); }
-          __syncthreads();
+          lds_barrier();
           const float f0 = bc[0], f1 = bc[1];
           if (threadIdx.x == 0) { Scar[0] = (f0 == f0) ? (double)f0 : 0.0; Scar[1] = (f1 == f1) ? (double)f1 : 0.0; }
-          __syncthreads();
+          lds_barrier();
         }
         double ua[C], ub[C];
 #pragma unroll
@@ -150,10 +150,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         // applyOnePoleLP (final-filters.js:68-78): y starts at data[0]
         if (t == 0) {
           if (threadIdx.x == 0) bc[c] = f32r(d[0]);
-          __syncthreads();
+          lds_barrier();
           const float f0 = bc[c];
           if (threadIdx.x == 0) Scar[c] = (f0 == f0) ? (double)f0 : 0.0;
-          __syncthreads();
+          lds_barrier();
         }
         double u[C];
 #pragma unroll

@@ -27,19 +27,35 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
   __shared__ double Sst[2][2];                   // tile carries of the two cascaded instances
   if (wave_id() == 0) biquad_lane_power_table(hp->exc_hp, lane_id(), &Ptab[0][0]);
   if (threadIdx.x < 4) Sst[threadIdx.x >> 1][threadIdx.x & 1] = 0;
-  __syncthreads();
+  lds_barrier();
   const double mix = 0.15 / 100, drive = 0.5, bias = 0.2;     // constants.js:36-42, exciter.js:88
   // segment [T0, T1) of the tiles (blockIdx.y), entered `warm` tiles early: the only state is two 6 kHz high-passes
   const int64_t ntiles = (n + kTile - 1) / kTile;
   const int64_t T0 = (int64_t)blockIdx.y * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
   const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+#if WAM_EXC_PROBE == 3
+  float nv[C], nva, nvb;
+  auto fetch = [&](int64_t t) {
+    const int64_t b = t * kTile + (int64_t)threadIdx.x * C;
+    load_chunk(x, n, b, nv);
+    nva = b + C < n ? x[b + C] : 0.0f; nvb = b + C + 1 < n ? x[b + C + 1] : 0.0f;
+  };
+  fetch(Tw);
+#endif
   for (int64_t t = Tw; t < T1; t++) {
     const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     float v[C];
+#if WAM_EXC_PROBE == 3
+#pragma unroll
+    for (int k = 0; k < C; k++) v[k] = nv[k];
+    float va = nva, vb = nvb;
+    if (t + 1 < T1) fetch(t + 1);
+#else
     load_chunk(x, n, base, v);
     float va = base + C < n ? x[base + C] : 0.0f, vb = base + C + 1 < n ? x[base + C + 1] : 0.0f;
+#endif
     if (pre_gain != 1.0) {
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * pre_gain);
@@ -56,45 +72,57 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < C; k++) { xin[k] = v[k]; d[k] = v[k]; }
     double s0, s1;
-    biquad_chunk_lds(d, pv[1], pv[0], P.exc_hp, &Ptab[0][0], Sst[0], slots.next(), s0, s1);
     double ea, eb;
+#if WAM_EXC_PROBE == 5
+    s0 = pv[1]; s1 = pv[0]; ea = va; eb = vb;
+#else
+    biquad_chunk_lds(d, pv[1], pv[0], P.exc_hp, &Ptab[0][0], Sst[0], slots.next(), s0, s1);
     biquad_extra2(d, xin, va, vb, P.exc_hp, ea, eb);
+#endif
     double f1[C];
 #pragma unroll
     for (int k = 0; k < C; k++) { f1[k] = (double)f32r(d[k]); d[k] = f1[k]; }
     const double f1a = (double)f32r(ea), f1b = (double)f32r(eb);
     double u0, u1;
-    biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, &Ptab[0][0], Sst[1], slots.next(), u0, u1);
     double ga, gb;
+#if WAM_EXC_PROBE == 2 || WAM_EXC_PROBE == 5
+    u0 = s0; u1 = s1; ga = ea; gb = eb;
+#else
+    biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, &Ptab[0][0], Sst[1], slots.next(), u0, u1);
     biquad_extra2(d, f1, f1a, f1b, P.exc_hp, ga, gb);
+#endif
     // filtered[i-1 .. i+2] around each sample; out-of-range reads AND NaN are 0 (`filtered[k] || 0`, exciter.js:162-184: after a
     // NaN input sample the filter state stays NaN and the reference's wet path falls back to tanh(bias))
-    double f[C + 3];
-    f[0] = (base - 1 >= 0) ? (double)f32r(u0) : 0.0;
+    float f[C + 3];                                // (kept as the f32 values they are: half the registers across the shaping loop)
+    f[0] = (base - 1 >= 0) ? f32r(u0) : 0.0f;
 #pragma unroll
-    for (int k = 0; k < C; k++) f[k + 1] = (base + k < n) ? (double)f32r(d[k]) : 0.0;
-    f[C + 1] = (base + C < n) ? (double)f32r(ga) : 0.0;
-    f[C + 2] = (base + C + 1 < n) ? (double)f32r(gb) : 0.0;
+    for (int k = 0; k < C; k++) f[k + 1] = (base + k < n) ? f32r(d[k]) : 0.0f;
+    f[C + 1] = (base + C < n) ? f32r(ga) : 0.0f;
+    f[C + 2] = (base + C + 1 < n) ? f32r(gb) : 0.0f;
 #pragma unroll
-    for (int k = 0; k < C + 3; k++) f[k] = (f[k] == f[k]) ? f[k] : 0.0;
+    for (int k = 0; k < C + 3; k++) f[k] = (f[k] == f[k]) ? f[k] : 0.0f;
     float o[C];
     // |tanh argument| <= 1 for the whole wavefront's chunks (the Catmull-Rom midpoint overshoots its neighbours by at most 1.25):
     // the Pade form; else the general one.  High-passed programme material is far below the bound.
-    double fmx = 0;
+    float fmx = 0;
 #pragma unroll
-    for (int k = 0; k < C + 3; k++) fmx = fmax(fmx, fabs(f[k]));
+    for (int k = 0; k < C + 3; k++) fmx = fmaxf(fmx, fabsf(f[k]));
     auto shape = [&](auto tanh_fn) {
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const double wetA = tanh_fn(f[k + 1] * drive + bias);
-        const double sB = catmull_half(f[k], f[k + 1], f[k + 2], f[k + 3]);
+        const double wetA = tanh_fn((double)f[k + 1] * drive + bias);
+        const double sB = catmull_half((double)f[k], (double)f[k + 1], (double)f[k + 2], (double)f[k + 3]);
         const double wetB = tanh_fn(sB * drive + bias);
         const double wet = (wetA + wetB) * 0.5;
         o[k] = f32r((double)v[k] + wet * mix);
       }
     };
-    if (__all(fmx * (1.25 * drive) + bias <= 1.0)) shape([](double z) { return tanh_small(z); });
+#if WAM_EXC_PROBE == 1 || WAM_EXC_PROBE == 5
+    for (int k = 0; k < C; k++) o[k] = f32r((double)v[k] + (double)(f[k] + f[k + 1] + f[k + 2] + f[k + 3]) * mix);
+#else
+    if (__all((double)fmx * (1.25 * drive) + bias <= 1.0)) shape([](double z) { return tanh_small(z); });
     else shape([](double z) { return tanh_fast(z); });
+#endif
     if (t >= T0) store_chunk(y, n, base, o);
   }
 }
@@ -147,7 +175,7 @@ __global__ __launch_bounds__(64) void k_warm_env(const unsigned* __restrict__ wi
       else ev = 0.0f;
       ev_s[i] = ev;
     }
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) {
       int i = 0;
       if (c0 == 0) { prev = ev_s[0]; sm_s[0] = prev; i = 1; }           // smoothed[0] = envelope[0]
@@ -173,9 +201,9 @@ __global__ __launch_bounds__(64) void k_warm_env(const unsigned* __restrict__ wi
         sm_s[i] = prev;
       }
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = lane; i < m; i += 64) s[c0 + i] = sm_s[i];
-    __syncthreads();
+    lds_barrier();
   }
 }
 // the look-ahead shift (:255-268): envelope[w] = smoothed[min(w + lookaheadWindows, numWindows - 1)]
@@ -214,7 +242,7 @@ __device__ __forceinline__ void split_init(SplitState& st, const Biquad& lp1, co
     biquad_lane_power_table(lp2, lane_id(), &st.P[2][0][0]); biquad_lane_power_table(hp2, lane_id(), &st.P[3][0][0]);
   }
   if (threadIdx.x < 16) st.S[threadIdx.x >> 1][threadIdx.x & 1] = 0;
-  __syncthreads();
+  lds_barrier();
 }
 // Bands are handed to `consume(band_index, float band[C])` one at a time (low, mid, high) so that only one band
 // is live in registers while it is processed.

@@ -22,7 +22,7 @@ __device__ __forceinline__ double block_excl_sum(double v, double& total, double
   inc += dpp_d<0x111, 0xF>(0.0, inc); inc += dpp_d<0x112, 0xF>(0.0, inc); inc += dpp_d<0x114, 0xF>(0.0, inc); inc += dpp_d<0x118, 0xF>(0.0, inc);
   inc += dpp_d<0x142, 0xA>(0.0, inc); inc += dpp_d<0x143, 0xC>(0.0, inc);          // rows, then the row aggregates (wam_device.hpp)
   if (lane == 63) lds[wave] = inc;
-  __syncthreads();
+  lds_barrier();
   double off = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) { if (w < wave) off += lds[w]; tot += lds[w]; }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
   const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
   const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
-  __syncthreads();
+  lds_barrier();
   auto gained = [&](float x) -> float { return f32r((double)x * G); };               // stage 8's Float32Array (normalizer.js:50-72)
   // soft-clipper.js:198-216 for the sample a = |input[i]| over the threshold: its ramp, clipped to this tile's window
   auto scatter = [&](int64_t i, double a, int64_t tile_base) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
         if (a > P.thr_lin) scatter(i, a, tile_base);
       }
     }
-    __syncthreads();
+    lds_barrier();
     float gs[C], g[C];
 #pragma unroll
     for (int k = 0; k < C; k++) { const float gv = __uint_as_float(gwin[threadIdx.x * C + k]); gs[k] = base + k < n ? gv : 1.0f; }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (emit) {
       // gain and 2x Catmull-Rom oversampled saturation (:234-286) of this thread's chunk; s = gained input x envelope at base-1 .. base+C+1
       float gv[C + 3];
@@ -201,14 +201,14 @@ __global__ __launch_bounds__(kThreads) void k_sc(const float* __restrict__ in, f
         store_chunk(out + (trk * NCH + c) * n, n, base, o);
       }
     }
-    __syncthreads();                                      // the window and the exchange arrays have been read
+    lds_barrier();                                      // the window and the exchange arrays have been read
     if (threadIdx.x == kThreads - 1) {
       carry[0] = g[C - 1];
 #pragma unroll
       for (int c = 0; c < NCH; c++) carry[1 + c] = v[c][C - 1];
     }
     for (int i = threadIdx.x; i < kWin; i += kThreads) gwin[i] = one;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   double Spk = 0;
   int ring = 0;                                        // stays 0 while W <= kTile
   for (int i = threadIdx.x; i < padi(W) + 8; i += kThreads) tail[i] = 0;
-  __syncthreads();
+  lds_barrier();
   // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact once W samples (10 ms; the
   // warm-up is 25 tiles at 48 kHz and scales with the rate) have been seen, and the peak follower forgets as exp(-k / (50 ms))
   const int64_t ntiles = (n + kTile - 1) / kTile;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
       tmv[k] = tmk;
     }
     if (t >= T0) store_chunk(tmo, n, base, tmv);
-    __syncthreads();
+    lds_barrier();
     // next tile's tail = the last W prefixes, re-based to the next tile's origin (minus this tile's total): from this tile
     // alone when W <= kTile; else the ring turns by one tile, its newest kTile entries come from this tile and the older
     // ones are re-based in place.  (All reads of tail for this tile lie before the barrier above.)
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
         else tail[padi(ph)] -= total;
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -305,7 +305,9 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
   extern __shared__ float gwin_s[];             // gain envelope of [tile_base - L, tile_end): L + kTile floats of dynamic LDS
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[NCH][kCtxFloats];
-  volatile float* gwin = gwin_s;
+  // (volatile: lanes read what other lanes of the wavefront wrote; in the LDS address space - a generic volatile pointer makes
+  // every access a system-coherent FLAT operation)
+  volatile float __attribute__((address_space(3)))* gwin = (volatile float __attribute__((address_space(3)))*)gwin_s;
   const LimiterPlan& P = *lp;
   const int L = P.L;
   const int64_t trk = blockIdx.y;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
   LdsSlots slots(lds_scan);
   double Scur = 1.0;
   for (int i = threadIdx.x; i < L + kTile; i += kThreads) gwin[i] = 1.0f;
-  __syncthreads();
+  lds_barrier();
   const int lane = lane_id(), wave = wave_id();
   // segment [T0, T1) of the tiles, entered `warm` tiles early (release memory exp(-k / (100 ms)); ramps reach back L)
   const int64_t ntiles = (n + L + kTile - 1) / kTile;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     // finalised samples [tile_base - L, tile_end - L): release smoothing (dsp-worker.js:416-425)
     const int64_t kb = tile_base - L + (int64_t)threadIdx.x * C;
@@ -402,12 +404,12 @@ __global__ __launch_bounds__(kThreads) void k_lim_gain(const float* __restrict__
       if (kb >= 0) store_chunk(go, n, kb, g);
       else { for (int k = 0; k < C; k++) if (kb + k >= 0 && kb + k < n) go[kb + k] = g[k]; }
     }
-    __syncthreads();
+    lds_barrier();
     // slide the window by one tile: [kTile, kTile + L) -> [0, L) (disjoint, L <= kTile), then the rest back to 1.0
     for (int i = threadIdx.x; i < L; i += kThreads) gwin[i] = gwin[kTile + i];
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < kTile; i += kThreads) gwin[L + i] = 1.0f;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_apply(const float* __restrict_
   __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
   MeterStateL ms;
   if (mp) meter_init_l(ms, *mp, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
-  __syncthreads();
+  lds_barrier();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;

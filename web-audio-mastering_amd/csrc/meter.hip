@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kThreads) void k_meter(const float* __restrict__ in
   __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
   MeterStateL m;
   meter_init_l(m, pl, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
-  __syncthreads();
+  lds_barrier();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void k_gain_meter(const float* __restrict
   __shared__ double mP[2][64 * 4], mS[2][2];        // K-weighting lane powers and tile carries (meter_init_l)
   MeterStateL m;
   meter_init_l(m, pl, sg.Tw * kTile, sg, mP[0], mP[1], mS[0], mS[1]);
-  __syncthreads();
+  lds_barrier();
   for (int64_t t = sg.Tw; t < sg.T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
   if (h_last > m.hop_hi - 1) h_last = m.hop_hi - 1;
   double* part = lds + 16;
   for (int64_t h0 = h_first; h0 <= h_last; h0 += 4) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int64_t h = h0 + j;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void meter_hop_part(const double v[C], int64_t base, 
       c = wave_sum_lane63(c);
       if (lane_id() == 63) part[wave_id() * 4 + j] = c;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 4) {
       // thread (h & 3) owns hop h in every tile, so the read-modify-write below is same-thread ordered
       const int j = (int)((threadIdx.x - h0) & 3);
@@ -187,9 +187,9 @@ __device__ __forceinline__ void meter_chunk_l2(const float xa[C], const float xp
 template <class St>
 __device__ __forceinline__ void meter_finish(St& m, double* lds, double* peak_out) {
   const double w = wave_max(m.peak);
-  __syncthreads();
+  lds_barrier();
   if (lane_id() == 0) lds[wave_id()] = w;
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) {
     const double pk = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
     atomicMax(reinterpret_cast<unsigned long long*>(peak_out), (unsigned long long)__double_as_longlong(pk));

@@ -44,6 +44,17 @@ struct OnePole {           // y[n] = c y[n-1] + u[n]
 };
 
 // ---- small helpers ---------------------------------------------------------
+// Workgroup barrier for data that is exchanged through LDS only.  __syncthreads() fences every address space: the compiler puts
+// s_waitcnt vmcnt(0) in front of each one, so a wavefront sits out the latency of the tile's global loads at the first barrier and
+// drains its stores of the previous tile there too - memory time added to compute time instead of hidden under it (k_exciter
+// reduced to load + store took 9.6 of its 20 ms per 256 tracks).  This one orders LDS only: loads in flight stay in flight
+// until their first use, stores retire in the background.  (Nothing in the tile kernels hands data from thread to thread
+// through global memory inside a launch; a kernel that does - k_gate's masks - keeps __syncthreads().)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // The same number as a scalar.  Work that is handed out per WAVEFRONT (frames, segments) must be indexed with this one: derived
@@ -55,10 +66,16 @@ __device__ __forceinline__ float f32r(double v) { return (float)v; }   // the Fl
 // Make a plan pointer opaque once per tile: the compiler then reloads plan constants through the
 // scalar cache where they are used instead of hoisting hundreds of them out of the tile loop and
 // spilling them to VGPR lanes (v_writelane/v_readlane cost VALU issue slots; s_load does not).
+// The opaque step also hides where the pointer came from: left generic, every plan constant is then a FLAT vector load (64 lanes
+// fetching one address through the texture path, counted on vmcnt AND lgkmcnt, so each forces a full s_waitcnt - 289 of them in
+// k_front<2>).  The plans are written by the host before the launch and never by a kernel, so the pointer goes through the
+// asm in the constant address space, and the loads behind it are s_load again.
 template <class T>
 __device__ __forceinline__ const T* reload_each_tile(const T* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+  typedef const T __attribute__((address_space(4)))* cptr;
+  cptr c = (cptr)p;
+  asm volatile("" : "+s"(c));
+  return (const T*)c;
 }
 
 // num / den for operands in a "safe" range (no overflow / underflow / zero of den, |quotient| moderate): v_rcp_f64 (measured on
@@ -339,7 +356,7 @@ __device__ __forceinline__ void biquad_chunk_lds(double x[C], double xm1, double
                                                  double* lds, double& s0, double& s1) {
   BiquadMid m;
   biquad_pre(x, xm1, xm2, q, Plds, Slds, lds + 2 * wave_id(), m);
-  __syncthreads();
+  lds_barrier();
   biquad_post(x, q, Plds, Slds, lds, m, s0, s1);
 }
 // Two independent stages (two filters on one input, or one filter on two channels) under ONE barrier; their dependent
@@ -350,7 +367,7 @@ __device__ __forceinline__ void biquad_pair_lds(double xa[C], double xam1, doubl
   BiquadMid ma, mb;
   biquad_pre(xa, xam1, xam2, qa, Pa, Sa, lds + 2 * wave_id(), ma);
   biquad_pre(xb, xbm1, xbm2, qb, Pb, Sb, lds + 8 + 2 * wave_id(), mb);
-  __syncthreads();
+  lds_barrier();
   biquad_post(xa, qa, Pa, Sa, lds, ma, sa0, sa1);
   biquad_post(xb, qb, Pb, Sb, lds + 8, mb, sb0, sb1);
 }
@@ -364,7 +381,7 @@ __device__ __forceinline__ void scan1(double& e, const OnePole& q, double Pl, do
   wave_scan_affine(al, e);
   if (lane == 63) lds[wave] = e;
   const double x = dpp_d<0x138, 0xF>(0.0, e);
-  __syncthreads();
+  lds_barrier();
   double w = S, my = S;
 #pragma unroll
   for (int k = 0; k < kWaves; k++) {
@@ -399,7 +416,7 @@ __device__ __forceinline__ void onepole_pair(double ua[C], double ub[C], const O
   wave_scan_affine(alb, pb);
   if (lane == 63) { lds[wave] = pa; lds[4 + wave] = pb; }
   const double xa = dpp_d<0x138, 0xF>(0.0, pa), xb = dpp_d<0x138, 0xF>(0.0, pb);
-  __syncthreads();
+  lds_barrier();
   double wa = Sa, wb = Sb, mya = Sa, myb = Sb;
 #pragma unroll
   for (int k = 0; k < kWaves; k++) {
@@ -421,7 +438,7 @@ __device__ __forceinline__ double scan_affine(double al, double be, double& S, d
   wave_scan_affine(al, be);
   if (lane == 63) { lds[2 * wave] = al; lds[2 * wave + 1] = be; }
   const double xa = dpp_d<0x138, 0xF>(1.0, al), xb = dpp_d<0x138, 0xF>(0.0, be);
-  __syncthreads();
+  lds_barrier();
   double w = S, my = S;
 #pragma unroll
   for (int k = 0; k < kWaves; k++) {
@@ -460,7 +477,7 @@ __device__ __forceinline__ bool block_any(bool p, int& parity) {
   int* f = flags[parity];
   parity ^= 1;
   if (lane_id() == 0) f[wave_id()] = w;
-  __syncthreads();
+  lds_barrier();
   const int4 v = *reinterpret_cast<const int4*>(f);
   return (v.x | v.y | v.z | v.w) != 0;
 }
@@ -580,7 +597,7 @@ __device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1
       v2f xa, xb;
       xa.x = dpp_f<0x138, 0xF>(1.0f, al.x); xa.y = dpp_f<0x138, 0xF>(1.0f, al.y);
       xb.x = dpp_f<0x138, 0xF>(0.0f, be.x); xb.y = dpp_f<0x138, 0xF>(0.0f, be.y);
-      __syncthreads();
+      lds_barrier();
       v2f w = Sin, my = Sin;
 #pragma unroll
       for (int k = 0; k < kWaves; k++) {
@@ -590,7 +607,7 @@ __device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1
       }
       st = xa * my + xb;
     }
-    __syncthreads();                                              // the loop below rewrites the slot
+    lds_barrier();                                              // the loop below rewrites the slot
     s1 = (double)st.x; s2 = (double)st.y;
   }
 #endif
@@ -629,7 +646,7 @@ __device__ __forceinline__ void follower_solve2(const T& a, double A1, double R1
     if (lane == 63) { lds[4 * wave] = al1; lds[4 * wave + 1] = be1; lds[4 * wave + 2] = al2; lds[4 * wave + 3] = be2; }
     const double xa1 = dpp_d<0x138, 0xF>(1.0, al1), xb1 = dpp_d<0x138, 0xF>(0.0, be1);
     const double xa2 = dpp_d<0x138, 0xF>(1.0, al2), xb2 = dpp_d<0x138, 0xF>(0.0, be2);
-    __syncthreads();
+    lds_barrier();
     double w1 = S1_in, w2 = S2_in, my1 = S1_in, my2 = S2_in;
 #pragma unroll
     for (int k = 0; k < kWaves; k++) {
@@ -726,7 +743,7 @@ __device__ __forceinline__ void prev_context(const float last[K], float prev[K],
   const int t = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < K; k++) cur[(t + 1) * K + k] = last[k];
-  __syncthreads();
+  lds_barrier();
   if (t == 0) {
 #pragma unroll
     for (int k = 0; k < K; k++) prev[k] = first_tile ? 0.0f : old[kThreads * K + k];
@@ -750,7 +767,7 @@ __device__ __forceinline__ void prev_ctx(const float last[K], float prev[K], flo
 #pragma unroll
     for (int k = 0; k < K; k++) cur[wave * K + k] = last[k];
   }
-  __syncthreads();
+  lds_barrier();
   if (lane == 0) {
     if (wave == 0) {
 #pragma unroll
@@ -774,7 +791,7 @@ __device__ __forceinline__ void prev_ctx2(const float lastA[K], float prevA[K], 
 #pragma unroll
     for (int k = 0; k < K; k++) { curA[wave * K + k] = lastA[k]; curB[wave * K + k] = lastB[k]; }
   }
-  __syncthreads();
+  lds_barrier();
   if (lane == 0) {
     if (wave == 0) {
 #pragma unroll
