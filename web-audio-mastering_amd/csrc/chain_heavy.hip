@@ -34,28 +34,25 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
   const int64_t T0 = (int64_t)blockIdx.y * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
   const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
-#if WAM_EXC_PROBE == 3
+  // The next tile's samples are requested before this tile is computed, and nothing else is loaded inside the loop: vmcnt counts
+  // loads in order, so waiting for any later load would wait for the prefetch as well.
   float nv[C], nva, nvb;
   auto fetch = [&](int64_t t) {
     const int64_t b = t * kTile + (int64_t)threadIdx.x * C;
     load_chunk(x, n, b, nv);
     nva = b + C < n ? x[b + C] : 0.0f; nvb = b + C + 1 < n ? x[b + C + 1] : 0.0f;
   };
+  float pm[2] = { 0.0f, 0.0f };                           // a later segment starts from the samples in memory
+  if (Tw > 0 && threadIdx.x == 0) { pm[0] = x[Tw * kTile - 2]; pm[1] = x[Tw * kTile - 1]; }
   fetch(Tw);
-#endif
   for (int64_t t = Tw; t < T1; t++) {
     const HeavyPlan& P = *reload_each_tile(hp);
     const int64_t base = t * kTile + (int64_t)threadIdx.x * C;
     float v[C];
-#if WAM_EXC_PROBE == 3
 #pragma unroll
     for (int k = 0; k < C; k++) v[k] = nv[k];
     float va = nva, vb = nvb;
     if (t + 1 < T1) fetch(t + 1);
-#else
-    load_chunk(x, n, base, v);
-    float va = base + C < n ? x[base + C] : 0.0f, vb = base + C + 1 < n ? x[base + C + 1] : 0.0f;
-#endif
     if (pre_gain != 1.0) {
 #pragma unroll
       for (int k = 0; k < C; k++) v[k] = f32r((double)v[k] * pre_gain);
@@ -64,8 +61,8 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     const float last[2] = { v[C - 2], v[C - 1] };
     float pv[2];
     prev_ctx<2>(last, pv, ctx[0], (int)(t & 1), t == Tw);
-    if (t == Tw && Tw > 0 && threadIdx.x == 0) {          // a later segment starts from the samples in memory
-      pv[0] = x[base - 2]; pv[1] = x[base - 1];
+    if (t == Tw && Tw > 0 && threadIdx.x == 0) {
+      pv[0] = pm[0]; pv[1] = pm[1];
       if (pre_gain != 1.0) { pv[0] = f32r((double)pv[0] * pre_gain); pv[1] = f32r((double)pv[1] * pre_gain); }
     }
     double xin[C], d[C];
@@ -73,24 +70,16 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     for (int k = 0; k < C; k++) { xin[k] = v[k]; d[k] = v[k]; }
     double s0, s1;
     double ea, eb;
-#if WAM_EXC_PROBE == 5
-    s0 = pv[1]; s1 = pv[0]; ea = va; eb = vb;
-#else
     biquad_chunk_lds(d, pv[1], pv[0], P.exc_hp, &Ptab[0][0], Sst[0], slots.next(), s0, s1);
     biquad_extra2(d, xin, va, vb, P.exc_hp, ea, eb);
-#endif
     double f1[C];
 #pragma unroll
     for (int k = 0; k < C; k++) { f1[k] = (double)f32r(d[k]); d[k] = f1[k]; }
     const double f1a = (double)f32r(ea), f1b = (double)f32r(eb);
     double u0, u1;
     double ga, gb;
-#if WAM_EXC_PROBE == 2 || WAM_EXC_PROBE == 5
-    u0 = s0; u1 = s1; ga = ea; gb = eb;
-#else
     biquad_chunk_lds(d, (double)f32r(s0), (double)f32r(s1), P.exc_hp, &Ptab[0][0], Sst[1], slots.next(), u0, u1);
     biquad_extra2(d, f1, f1a, f1b, P.exc_hp, ga, gb);
-#endif
     // filtered[i-1 .. i+2] around each sample; out-of-range reads AND NaN are 0 (`filtered[k] || 0`, exciter.js:162-184: after a
     // NaN input sample the filter state stays NaN and the reference's wet path falls back to tanh(bias))
     float f[C + 3];                                // (kept as the f32 values they are: half the registers across the shaping loop)
@@ -117,12 +106,8 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
         o[k] = f32r((double)v[k] + wet * mix);
       }
     };
-#if WAM_EXC_PROBE == 1 || WAM_EXC_PROBE == 5
-    for (int k = 0; k < C; k++) o[k] = f32r((double)v[k] + (double)(f[k] + f[k + 1] + f[k + 2] + f[k + 3]) * mix);
-#else
     if (__all((double)fmx * (1.25 * drive) + bias <= 1.0)) shape([](double z) { return tanh_small(z); });
     else shape([](double z) { return tanh_fast(z); });
-#endif
     if (t >= T0) store_chunk(y, n, base, o);
   }
 }
