@@ -93,6 +93,29 @@ def test_chain_segments_long():
     assert abs(res.lufs - rres.lufs) <= 0.01
 
 
+@pytest.mark.parametrize("sr", [48000, 44100, 96000, 11025])
+def test_exciter_window_peaks_equal_the_separate_pass(sr):
+    """The exciter leaves tape warmth's per-window peaks behind (k_exciter<PEAKS>, every 4th sample of each 100 ms window, maximum
+    over the channels); with the hook off, k_win_peak reads the exciter's output again.  Maxima are order-independent: the chain's
+    output must be the same to the bit, with one segment and with many seams (window boundaries inside wavefronts, chunks and tiles:
+    4,410 and 1,102 are not multiples of 16).  At 11,025 Hz the window (1,102 samples) is shorter than the fused form allows
+    (a wavefront's 1,024 samples + a chunk), so both runs take the separate pass."""
+    x = O.synth(9, 2, int(7.3 * sr) + 331, sr, {"amp": 0.9, "clickAmp": 0.6})          # quiet enough for the bypass envelope to move
+    s = dict(wam.DEFAULT_SETTINGS, addAir=True, tapeWarmth=True)
+    for seg in (1 << 20, 5):
+        wam.tune("fx_seg_tiles", seg)
+        wam.tune("exc_peaks", 0)
+        want, wres = wam.render_full_chain(x, sr, s, "export")
+        wam.tune("exc_peaks", 1)
+        got, gres = wam.render_full_chain(x, sr, s, "export")
+        for a, b in zip(got, want):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), (sr, seg)
+        assert gres.lufs == wres.lufs
+    if sr == 48000:
+        ref, _ = O.render_chain(x, sr, s, "export")
+        assert maxerr(got, ref) <= TOL
+
+
 def test_fx_segments(hot):
     """exciter / tape warmth / punch: LTI state needs 2 warm-up tiles, the slow transient follower 48."""
     sr, x0 = hot

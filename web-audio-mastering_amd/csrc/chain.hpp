@@ -58,9 +58,11 @@ int enqueue_limiter(const float* in, float* out, float* tm, float* genv, int ntr
                     int preserve, const MeterPlan* meter_dev, double* hopsums, int64_t hop_stride, double* peaks, double sr, hipStream_t s,
                     const Progress* prog = nullptr);
 
-int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s);
+bool exciter_makes_peaks(const HeavyPlan& hp_host);
+int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s,
+                    unsigned* winpeak = nullptr, const HeavyPlan* hp_host = nullptr);
 int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const HeavyPlan& hp_host, unsigned* winpeak, float* sm, float* env,
-                     double pre_gain, hipStream_t s);
+                     double pre_gain, hipStream_t s, bool have_peaks = false);
 int enqueue_warm_punch(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, int do_warm, int do_punch,
                        const float* env, double pre_gain, double sr, hipStream_t s);
 void make_heavy_plan(double sr, int64_t n, HeavyPlan* p);

@@ -235,15 +235,17 @@ static int render_group(const float* in, float* out, int T, int nch, int64_t n, 
     rc = enqueue_deharsh(src, dst, T, nch, n, sr, pending_gain, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
+  bool peaks_made = false;
   if (do_exc) {
     rc = prog(0.3, "Applying exciter..."); if (rc) return rc;
     float* dst = next_dst();
-    rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, sr, stream); if (rc) return rc;
+    peaks_made = do_warm && exciter_makes_peaks(hp);      // tape warmth's window peaks come out of the exciter's registers
+    rc = enqueue_exciter(src, dst, T, nch, n, hp_d, pending_gain, sr, stream, peaks_made ? wpk.as<unsigned>() : nullptr, &hp); if (rc) return rc;
     src = dst; pending_gain = 1.0;
   }
   if (do_warm) {
     rc = prog(0.45, "Applying multiband saturation..."); if (rc) return rc;
-    rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream); if (rc) return rc;
+    rc = enqueue_warm_env(src, T, nch, n, hp, wpk.as<unsigned>(), wsm.as<float>(), wenv.as<float>(), pending_gain, stream, peaks_made); if (rc) return rc;
     float* dst = next_dst();
     rc = enqueue_warm_punch(src, dst, T, nch, n, hp_d, 1, 0, wenv.as<float>(), pending_gain, sr, stream); if (rc) return rc;
     src = dst; pending_gain = 1.0;
@@ -462,9 +464,11 @@ int wam_batch_render_dev(const float* in_dev, int ntracks, int nch, int64_t n, d
   return render_batch_dev(in_dev, out_dev, ntracks, nch, n, sr, settings, mode, results, (hipStream_t)stream, nullptr, nullptr);
 }
 
-// Host-pointer batch on ONE device.  Tracks go through the device in staging groups of `host_group` tracks (32: a group's 64
-// channels fill the chip with little time segmentation; groups of 8 spent 261 ms in kernels per 128 tracks where one batch takes
-// 184); up to `max_workers` host threads, each with its own stream and device buffers, pull groups from a shared counter, so
+// Host-pointer batch on ONE device.  Tracks go through the device in staging groups of `host_group` tracks (16: eight groups per
+// 128 tracks pipeline copies against kernels better than four, and time segmentation fills the chip from 32 channels; measured
+// on the MI355X box, 128 tracks, best of three / typical: groups of 8: 382 / 390 ms, 16: 355 / 405 ms, 32: 427 / 435 ms -
+// tools/host_path_timing.py with WAM_HOST_SWEEP=1; the run-to-run spread is the host's, the copies are CPU-memcpy bound);
+// up to `max_workers` host threads, each with its own stream and device buffers, pull groups from a shared counter, so
 // some groups' copies run while other groups' kernels do.  The copies go through the pinned rings of staging.hip (a ring and
 // stage_threads copy threads per worker while it copies).  Results are independent of
 // the split: tracks never interact.

@@ -15,8 +15,15 @@ __device__ __forceinline__ void biquad_extra2(const double y[C], const double x[
   yb = q.b0 * xb + q.b1 * xa + q.b2 * x[C - 1] - q.a1 * ya - q.a2 * y[C - 1];
 }
 
+// PEAKS: the exciter's output is tape warmth's input, whose bypass envelope starts from the per-window peaks of every 4th sample
+// (k_win_peak below: a pass over the whole batch at HBM speed).  With PEAKS the kernel takes them from the values it has in
+// registers: per chunk two running maxima (the chunk's window and the next one: a chunk crosses at most one boundary), reduced
+// over the wavefront - whose 1,024 samples lie in at most two windows, windows being longer than that (checked by the launcher) -
+// and merged with atomicMax on the float bit patterns, exactly as k_win_peak merges its partial maxima.
+template <bool PEAKS>
 __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ in, float* __restrict__ out, int64_t n,
-                                                      const HeavyPlan* __restrict__ hp, double pre_gain, int64_t seg_tiles, int64_t warm) {
+                                                      const HeavyPlan* __restrict__ hp, double pre_gain, int64_t seg_tiles, int64_t warm,
+                                                      int nch, unsigned* __restrict__ winpeak) {
   __shared__ double lds_scan[kSlotDoubles];
   __shared__ float ctx[1][kCtxFloats];
   const int64_t chan = blockIdx.x;
@@ -44,6 +51,13 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
   };
   float pm[2] = { 0.0f, 0.0f };                           // a later segment starts from the samples in memory
   if (Tw > 0 && threadIdx.x == 0) { pm[0] = x[Tw * kTile - 2]; pm[1] = x[Tw * kTile - 1]; }
+  // PEAKS: window of this thread's chunk start and the position in it, advanced tile by tile without divisions
+  const int ws = PEAKS ? (int)hp->w_ws : 1;
+  const int64_t nw = PEAKS ? hp->w_nw : 0;
+  int64_t win = PEAKS ? (T0 * kTile + (int64_t)threadIdx.x * C) / ws : 0;
+  int wpos = PEAKS ? (int)((T0 * kTile + (int64_t)threadIdx.x * C) % ws) : 0;
+  const int tile_q = kTile / ws, tile_r = kTile % ws;
+  unsigned* wpk = PEAKS ? winpeak + (chan / nch) * nw : nullptr;
   fetch(Tw);
   for (int64_t t = Tw; t < T1; t++) {
     const HeavyPlan& P = *reload_each_tile(hp);
@@ -109,6 +123,40 @@ __global__ __launch_bounds__(kThreads) void k_exciter(const float* __restrict__ 
     if (__all((double)fmx * (1.25 * drive) + bias <= 1.0)) shape([](double z) { return tanh_small(z); });
     else shape([](double z) { return tanh_fast(z); });
     if (t >= T0) store_chunk(y, n, base, o);
+    if constexpr (PEAKS) {
+      if (t >= T0) {
+        float pa = 0.0f, pb = 0.0f;                  // maxima of |o| over every 4th sample of window `win` / `win + 1` (multiband-saturation.js:218-230)
+        if (__any(wpos + C > ws || base + C > n)) {  // a window boundary or the end of the track inside some chunk of the wavefront (one tile in ~5)
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            int pos = wpos + k;
+            const bool nxt = pos >= ws;
+            if (nxt) pos -= ws;
+            const float a = fabsf(o[k]);
+            if ((pos & 3) == 0 && base + k < n) {    // NaN never wins, as in the reference's `sample > peak`
+              if (nxt) { if (a > pb) pb = a; } else if (a > pa) pa = a;
+            }
+          }
+        } else {                                     // one window, all sixteen samples inside the track: the four samples k = ph (mod 4)
+          const int ph = (-wpos) & 3;
+#pragma unroll
+          for (int j = 0; j < C / 4; j++) {
+            const float a = fabsf(ph == 0 ? o[4 * j] : ph == 1 ? o[4 * j + 1] : ph == 2 ? o[4 * j + 2] : o[4 * j + 3]);
+            if (a > pa) pa = a;
+          }
+        }
+        const int64_t wlo = ((int64_t)__builtin_amdgcn_readfirstlane((int)(win >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)win);
+        float m0 = win == wlo ? pa : 0.0f, m1 = win == wlo ? pb : pa;      // the wavefront's windows wlo, wlo + 1
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, d)); m1 = fmaxf(m1, __shfl_xor(m1, d)); }
+        if (lane_id() == 0) {
+          if (m0 > 0 && wlo < nw) atomicMax(&wpk[wlo], __float_as_uint(m0));
+          if (m1 > 0 && wlo + 1 < nw) atomicMax(&wpk[wlo + 1], __float_as_uint(m1));
+        }
+        win += tile_q; wpos += tile_r;
+        if (wpos >= ws) { wpos -= ws; win++; }
+      }
+    }
   }
 }
 
@@ -432,22 +480,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_warm_punch(const float* __restr
 }
 
 // ---------------------------------------------------------------------------- launchers
-int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s) {
+// winpeak (optional, [ntracks][hp_host->w_nw]): also leaves tape warmth's window peaks of the OUTPUT there (zeroed here first);
+// exciter_makes_peaks() says whether this sample rate allows it.
+bool exciter_makes_peaks(const HeavyPlan& hp_host) { return hp_host.w_ws >= kTile / 4 + C && tuning().exc_peaks != 0; }
+int enqueue_exciter(const float* in, float* out, int ntracks, int nch, int64_t n, const HeavyPlan* plan_dev, double pre_gain, double sr, hipStream_t s,
+                    unsigned* winpeak, const HeavyPlan* hp_host) {
   if (n <= 0) return WAM_OK;
   const int64_t ntiles = (n + kTile - 1) / kTile, warm = scale_warm(tuning().lti_warm_tiles, sr);
   const int64_t seg = pick_segment_tiles((int64_t)ntracks * nch, ntiles, warm, tuning().fx_seg_tiles);
-  WAM_LAUNCH("k_exciter", k_exciter, dim3(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg)), dim3(kThreads), s, in, out, n, plan_dev, pre_gain, seg, warm);
+  const dim3 grid(ntracks * nch, (unsigned)((ntiles + seg - 1) / seg));
+  if (winpeak) {
+    if (!hp_host || !exciter_makes_peaks(*hp_host)) { set_error("enqueue_exciter: window peaks asked for at a sample rate that does not allow them"); return WAM_ERR_INVALID; }
+    WAM_HIP(hipMemsetAsync(winpeak, 0, sizeof(unsigned) * (size_t)hp_host->w_nw * ntracks, s));
+    WAM_LAUNCH("k_exciter", k_exciter<true>, grid, dim3(kThreads), s, in, out, n, plan_dev, pre_gain, seg, warm, nch, winpeak);
+  } else {
+    WAM_LAUNCH("k_exciter", k_exciter<false>, grid, dim3(kThreads), s, in, out, n, plan_dev, pre_gain, seg, warm, nch, (unsigned*)nullptr);
+  }
   return WAM_OK;
 }
 
+// have_peaks: winpeak was filled by the stage before (enqueue_exciter)
 int enqueue_warm_env(const float* in, int ntracks, int nch, int64_t n, const HeavyPlan& hp_host, unsigned* winpeak, float* sm, float* env,
-                     double pre_gain, hipStream_t s) {
+                     double pre_gain, hipStream_t s, bool have_peaks) {
   if (n <= 0) return WAM_OK;
   const int64_t nw = hp_host.w_nw, ws = hp_host.w_ws;
   if (ws < C) { set_error("tape warmth needs a bypass window of at least %d samples (sample rate too low)", C); return WAM_ERR_INVALID; }
-  WAM_HIP(hipMemsetAsync(winpeak, 0, sizeof(unsigned) * (size_t)nw * ntracks, s));
-  int64_t bx = nw < 512 ? nw : 512;
-  WAM_LAUNCH("k_win_peak", k_win_peak, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, nch, n, ws, nw, winpeak, pre_gain);
+  if (!have_peaks) {
+    WAM_HIP(hipMemsetAsync(winpeak, 0, sizeof(unsigned) * (size_t)nw * ntracks, s));
+    int64_t bx = nw < 512 ? nw : 512;
+    WAM_LAUNCH("k_win_peak", k_win_peak, dim3((unsigned)bx, (unsigned)ntracks), dim3(kThreads), s, in, nch, n, ws, nw, winpeak, pre_gain);
+  }
   const double thr = std::pow(10, -24 / 20.0), kst = std::pow(10, (-24 - 6) / 20.0);          // multiband-saturation.js:210-211, preset :35
   WAM_LAUNCH("k_warm_env", k_warm_env, dim3((unsigned)ntracks), dim3(64), s, (const unsigned*)winpeak, ntracks, nw, thr, kst, sm);
   int64_t sx = (nw + 255) / 256; if (sx > 256) sx = 256;

@@ -102,50 +102,8 @@ __device__ __forceinline__ double tanh_small(double x) {
   return div_fast(x * p, q);
 }
 
-// tanh in double, |error| < 2e-15 absolute (the callers add the result to a signal that is then
-// rounded to f32).  tanh|x| = (1 - t) / (1 + t), t = exp(-2|x|): range reduction by ln 2,
-// degree-12 Taylor polynomial on |r| <= ln2/2, reciprocal by v_rcp_f64 + two Newton steps.
-__device__ __forceinline__ double tanh_fast(double x) {
-  const double ax = fabs(x);
-  const double z = -2.0 * fmin(ax, 20.0);                 // t < 5e-18 beyond: tanh rounds to 1
-  const double k = rint(z * 1.4426950408889634);
-  double r = fma(-k, 6.93147180369123816490e-01, z);      // ln2 hi / lo
-  r = fma(-k, 1.90821492927058770002e-10, r);
-  double p = 2.08767569878680989792e-09;                  // 1/12!
-  p = fma(p, r, 2.50521083854417187751e-08);
-  p = fma(p, r, 2.75573192239858906526e-07);
-  p = fma(p, r, 2.75573192239858906526e-06);
-  p = fma(p, r, 2.48015873015873015873e-05);
-  p = fma(p, r, 1.98412698412698412698e-04);
-  p = fma(p, r, 1.38888888888888888889e-03);
-  p = fma(p, r, 8.33333333333333333333e-03);
-  p = fma(p, r, 4.16666666666666666667e-02);
-  p = fma(p, r, 1.66666666666666666667e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  const double t = ldexp(p, (int)k);
-  const double d = 1.0 + t;
-  double y = __builtin_amdgcn_rcp(d);
-  y = fma(fma(-d, y, 1.0), y, y);
-  y = fma(fma(-d, y, 1.0), y, y);
-  const double m = (1.0 - t) * y;
-  return copysign(m, x);
-}
-
-// sqrt(x) for x = 0 or x in [1e-280, 1e280], error <= 1 ulp: v_rsq_f64 and the Goldschmidt / Newton pair that ocml's sqrt uses,
-// without its range scaling and class checks (10 instructions against 16); used where the result is rounded to f32.
-__device__ __forceinline__ double sqrt_fast(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  g = fma(fma(-g, g, x), h, g);
-  g = fma(fma(-g, g, x), h, g);
-  return x > 0 ? g : 0.0;
-}
-
-// exp(z) for |z| <= 40, relative error ~1e-15 (the exponential of tanh_fast on its own)
+// exp(z) for |z| <= 40, relative error ~1e-15: range reduction by ln 2 (hi / lo), degree-12 Taylor polynomial on |t| <= ln2 / 2.
+// tanh_fast and pow_fast are built on it.
 __device__ __forceinline__ double exp_fast(double z) {
   const double k = rint(z * 1.4426950408889634);
   double t = fma(-k, 6.93147180369123816490e-01, z);      // ln2 hi / lo
@@ -166,8 +124,34 @@ __device__ __forceinline__ double exp_fast(double z) {
   return ldexp(e, (int)k);
 }
 
+// tanh in double, |error| < 2e-15 absolute (the callers add the result to a signal that is then
+// rounded to f32).  tanh|x| = (1 - t) / (1 + t), t = exp_fast(-2|x|), reciprocal by v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double tanh_fast(double x) {
+  const double ax = fabs(x);
+  const double z = -2.0 * fmin(ax, 20.0);                 // t < 5e-18 beyond: tanh rounds to 1
+  const double t = exp_fast(z);
+  const double d = 1.0 + t;
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  const double m = (1.0 - t) * y;
+  return copysign(m, x);
+}
+
+// sqrt(x) for x = 0 or x in [1e-280, 1e280], error <= 1 ulp: v_rsq_f64 and the Goldschmidt / Newton pair that ocml's sqrt uses,
+// without its range scaling and class checks (10 instructions against 16); used where the result is rounded to f32.
+__device__ __forceinline__ double sqrt_fast(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0 ? g : 0.0;
+}
+
 // r^q for r in [2^-100, 2^100], |q ln r| <= 40, relative error ~1e-15: ln r = E ln 2 + 2 atanh((m - 1) / (m + 1)) with the
-// mantissa m in [sqrt(1/2), sqrt(2)) (odd series to s^21), then the exponential of tanh_fast.  ~55 instructions against ~250
+// mantissa m in [sqrt(1/2), sqrt(2)) (odd series to s^21), then exp_fast.  ~55 instructions against ~250
 // for ocml's pow; used where the reference stores the power into a Float32Array and a later stage amplifies any f32-ulp
 // difference (the glue gain ahead of the soft clipper).
 __device__ __forceinline__ double pow_fast(double r, double q) {
@@ -188,23 +172,7 @@ __device__ __forceinline__ double pow_fast(double r, double q) {
   p = fma(p, s2, 1.0);
   const double ln_r = fma((double)E, 6.93147180559945309417e-01, 2.0 * s * p);
   const double z = q * ln_r;
-  const double k = rint(z * 1.4426950408889634);
-  double t = fma(-k, 6.93147180369123816490e-01, z);      // ln2 hi / lo
-  t = fma(-k, 1.90821492927058770002e-10, t);
-  double e = 2.08767569878680989792e-09;                  // 1/12!
-  e = fma(e, t, 2.50521083854417187751e-08);
-  e = fma(e, t, 2.75573192239858906526e-07);
-  e = fma(e, t, 2.75573192239858906526e-06);
-  e = fma(e, t, 2.48015873015873015873e-05);
-  e = fma(e, t, 1.98412698412698412698e-04);
-  e = fma(e, t, 1.38888888888888888889e-03);
-  e = fma(e, t, 8.33333333333333333333e-03);
-  e = fma(e, t, 4.16666666666666666667e-02);
-  e = fma(e, t, 1.66666666666666666667e-01);
-  e = fma(e, t, 0.5);
-  e = fma(e, t, 1.0);
-  e = fma(e, t, 1.0);
-  return ldexp(e, (int)k);
+  return exp_fast(z);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
