@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Copy the summaries of one profiles/refresh.sh run from gpurun_out/<tag>/ into profiles/ (tracked).
-usage: python profiles/ingest.py <tag> <round-prefix, e.g. r01>"""
+usage: python profiles/ingest.py <tag> <round-prefix, e.g. r01> [--pmc-only]
+--pmc-only: just the PMC summaries (refresh.sh runs this on the GPU box between the counter passes and the bench runs, so that the
+bench lines price their kernels with counters of the very same build; the commit then comes from $WAM_COMMIT, the box has no .git)."""
 import os, shutil, subprocess, sys
 tag, pre = sys.argv[1], sys.argv[2]
+pmc_only = "--pmc-only" in sys.argv[3:]
 here = os.path.dirname(os.path.abspath(__file__)); root = os.path.dirname(here)
 src = os.path.join(root, "gpurun_out", tag)
-cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(here, b))
+cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(here, b)) if not pmc_only else None
 cp("bench.json", f"{pre}_chain_T1024_bench.json")
 cp("bench_meter.json", f"{pre}_meter_T1024_bench.json")
 cp("bench_under_rocprof.json", f"{pre}_chain_T1024_bench_under_rocprof.json")
 cp(os.path.join("trace", "trace_kernel_stats.csv"), f"{pre}_chain_T1024_kernel_stats.csv")
 for extra, name in (("bench_stft.json", "stft_T1024"), ("bench_single.json", "chain_single"), ("bench_longform.json", "chain_longform"), ("bench_T128.json", "chain_T128")):
-    if os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 0:
+    if not pmc_only and os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 0:
         cp(extra, f"{pre}_{name}_bench.json")
 NSC = 128 * 2 * 8640000      # sample-channels per launch in the PMC passes (128 tracks)
-head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("WAM_COMMIT", "")
 sys.path.insert(0, root)
 import bench  # noqa: E402
 here_digest = bench.source_digest()
