@@ -17,11 +17,12 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-# Two segmentations of the FULL chain agree stage by stage to one f32 rounding (<= 1.2e-7, tools/debug_seg.py), but the
-# chain amplifies such flips: the soft clipper's knee is 0.001 wide (soft-clipper.js:203-204 with range < 0), a slope of
-# ~550 around its threshold, so isolated clusters of 50-700 samples differ by up to ~1.3e-6 on an hour of audio.  The
-# bar for two valid evaluations is therefore half the parity bar, not the single-stage seam tolerance.
-CHAIN_SEAM_TOL = 5e-6
+# Two segmentations of the FULL chain.  Round 2 saw isolated clusters differing by up to 1.3e-6 on an hour of audio and put the
+# bar at 5e-6; the cause was not the seams but the biquad scans' power tables, whose error depended on where a
+# chunk sat in its segment.  With the quadruple-precision tables the two renders of the 60-minute track, and batch against
+# single renders of 3-minute tracks, are IDENTICAL (0 of 691,200,000 samples differ; printed below).  The bar allows a handful
+# of f32 flips from the warm-up residue (<= 1e-7 of a state), nothing more.
+CHAIN_SEAM_TOL = 1e-6
 wam = pytest.importorskip("wam")
 torch = pytest.importorskip("torch")
 
@@ -67,8 +68,9 @@ def test_longform_60min_96k():
     y2 = torch.empty_like(x)
     r2 = wam.batch_render_dev(x.data_ptr(), y2.data_ptr(), 1, 2, n, sr, SETTINGS, "export")[0]
     assert bool(torch.isfinite(y1).all())
+    print(f"longform: two segmentations differ by at most {float((y1 - y2).abs().max()):.3e}, {int(((y1 - y2).abs() > 2e-7).sum())} of {2 * n} samples above 2e-7")
     assert float((y1 - y2).abs().max()) <= CHAIN_SEAM_TOL
-    assert int(((y1 - y2).abs() > 2e-7).sum()) < n // 500           # and they are rare: isolated clusters
+    assert int(((y1 - y2).abs() > 2e-7).sum()) <= 64                # and they are rare
     assert abs(r1.lufs - r2.lufs) <= 1e-6 and abs(r1.true_peak_db - r2.true_peak_db) <= 1e-5
     assert abs(r1.gain_db - (-14.0 - r1.lufs_in)) <= 1e-9                # normalizer.js:50
     ceil_lin = 10 ** (-1.0 / 20)
@@ -87,6 +89,7 @@ def test_batch_track_equals_single_track_3min():
     one = torch.empty((1, 2, n), dtype=torch.float32, device="cuda")
     for t in (0, 7, T - 1):
         r = wam.batch_render_dev(x[t:t + 1].data_ptr(), one.data_ptr(), 1, 2, n, sr, SETTINGS, "export")[0]
+        print(f"track {t}: batch vs single render differ by at most {float((one[0] - y[t]).abs().max()):.3e}")
         assert float((one[0] - y[t]).abs().max()) <= CHAIN_SEAM_TOL
         assert abs(r.lufs - res[t].lufs) <= 1e-6 and abs(r.lufs_in - res[t].lufs_in) <= 1e-6
     lufs = np.array([r.lufs for r in res])
