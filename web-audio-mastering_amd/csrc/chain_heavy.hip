@@ -1,10 +1,11 @@
 // chain_heavy.hip - the "heavy FX" stages 2..4 of the export chain (dsp-worker.js:1511-1527):
-//   k_exciter  : Add Air, exciter.js:80-214 (two 6 kHz Butterworth high-passes, 2x oversampled tanh, additive mix)
-//   k_win_peak : per-100 ms-window peak of every 4th sample, max over channels (multiband-saturation.js:218-230)
+//   k_exciter  : Add Air, exciter.js:80-214 (two 6 kHz Butterworth high-passes, 2x oversampled tanh, additive mix);
+//                <PEAKS> also leaves tape warmth's window peaks of its output behind
+//   k_win_peak : per-100 ms-window peak of every 4th sample, max over channels (multiband-saturation.js:218-230), when the exciter did not
 //   k_warm_env : bypass envelope: soft knee, asymmetric smoothing, one-window lookahead (:232-268)
 //   k_warm_punch: Tape Warmth (LR4 3-band split + biased tanh, multiband-saturation.js:280-352) and/or
 //                Add Punch (LR4 split + fast/slow followers + smoothed gain, multiband-transient.js:15-263)
-// Workgroups: one per (track, channel) except k_warm_env (one thread per track).
+// Workgroups: one per (track, channel) and time segment, except k_warm_env (one wavefront per track).
 #include "chain.hpp"
 
 namespace wam {
