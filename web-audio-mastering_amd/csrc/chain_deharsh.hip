@@ -568,7 +568,15 @@ __device__ __forceinline__ void dft16_d(dcx v[16]) {
 // twl's k = 1..8 in LDS (what it has room for beside the exchange buffers) and read twB from global memory.
 struct WaveTwD { const dcx* l; const dcx* q; };
 constexpr int kTwlLds = 6;                                         // W1024^(lane k) kept in LDS for k = 1..6
-constexpr int kTwsLds = kTwq + kTwlLds * 64;                       // dcx entries: W64^(qk), then those
+constexpr int kTwqRow = 17;                                        // W64^(q k), k < 16, in rows of 17: the four q of a quad read four different 16-byte
+constexpr int kTwqLds = 4 * kTwqRow;                               // slots of the 256-byte bank row (in rows of 16 every read was a 4-way conflict)
+constexpr int kTwsLds = kTwqLds + kTwlLds * 64;                    // dcx entries: W64^(qk), then those
+// Bank conflicts of the 16-byte accesses (MI355X: ds_read_b128 is served in four groups of 16 lanes over a 256-byte bank row,
+// ds_write_b128 in eight groups of 8 contiguous lanes over 128 bytes; SQ_LDS_BANK_CONFLICT was 44 % of the LDS cycles of the two
+// default kernels before).  The spectrum Z[p], p < 1024, lives at slot p + 2 (p >> 6): a lane's results have p = a + 64 q + ...
+// (a = lane >> 2, q = lane & 3), so eight contiguous lanes store to slots a + 2 q (mod 8): all different, where the linear layout
+// put the four q of a quad on ONE slot (4-way on every store); rows of 64 stay contiguous for the bin-pair reads.
+__device__ __forceinline__ constexpr int zslot(int p) { return p + 2 * (p >> 6); }
 // The analysis / synthesis window.  The f32 Hann table is symmetric (win[i] == win[2047 - i], checked on the host when the
 // table is built), so its first half fits the LDS beside the twiddles: 512 float2; otherwise the kernels read the full
 // table from global memory.
@@ -584,7 +592,10 @@ __device__ __forceinline__ float2 window_pair(const WinSrc<SYM>& W, int m) {   /
   return make_float2(t.y, t.x);
 }
 __device__ __forceinline__ void load_tables_lds(dcx* tws, float2* winh, const dcx* __restrict__ twd, const float* __restrict__ wing) {
-  for (int i = threadIdx.x; i < kTwsLds; i += 256) tws[i] = i < kTwq ? twd[kTwl + i] : twd[i - kTwq];
+  for (int i = threadIdx.x; i < kTwsLds; i += 256) {
+    if (i < kTwqLds) { const int q = i / kTwqRow, k = i % kTwqRow; tws[i] = twd[kTwl + 16 * q + (k < 16 ? k : 0)]; }
+    else tws[i] = twd[i - kTwqLds];
+  }
   for (int i = threadIdx.x; i < kM / 2; i += 256) winh[i] = ((const float2*)wing)[i];
   lds_barrier();
 }
@@ -608,7 +619,7 @@ __device__ __forceinline__ void fft1024_wave_d(dcx v[16], dcx* ex, const WaveTwD
   for (int m = 0; m < 16; m++) v[m] = row[4 * m];
   dft16_d<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 16; k++) { const dcx w = T.q[16 * q + k]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
+  for (int k = 1; k < 16; k++) { const dcx w = T.q[kTwqRow * q + k]; v[k] = INV ? dmulc(v[k], w) : dmul(v[k], w); }
   // Last stage: the radix-4 over the four lanes of a quad.  In double a DPP exchange costs two moves per 32 bits moved (8 per
   // complex value and stage: 256 moves + selects per transform), so the quad is transposed through LDS instead: lane
   // (a, q) = (lane >> 2, lane & 3) stores its sixteen k2-values into row a, slot 4 k2 + ((q + (k2 >> 2)) & 3) - the skew
@@ -643,9 +654,11 @@ __device__ __forceinline__ float mix_dry_wet(float dry_in, double dry, float wet
   const double a = (double)dry_in * dry, b = (double)wet_in * wet;
   return f32r(a + b);
 }
-// slot of this lane's j-th result of fft1024_wave_d
+// index p of this lane's j-th result of fft1024_wave_d, and its slot zslot(p) (p >> 6 = q + 4 (j >> 2))
 __device__ __forceinline__ int wave_out_base_d() { const int lane = lane_id(); return (lane >> 2) + 64 * (lane & 3); }
 __device__ __forceinline__ int wave_out_index_d(int ob, int j) { return ob + 16 * (j & 3) + 256 * (j >> 2); }
+__device__ __forceinline__ int wave_out_slot_base_d() { const int lane = lane_id(); return (lane >> 2) + 66 * (lane & 3); }
+__device__ __forceinline__ int wave_out_slot_d(int os, int j) { return os + 16 * (j & 3) + 264 * (j >> 2); }
 struct BinPairD { dcx xe, t; };
 __device__ __forceinline__ BinPairD split_pair_d(dcx zk, dcx zm, dcx w) {
   const dcx bq{ zm.x, -zm.y };
@@ -762,7 +775,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
   const float* x = in + chan * n;
   const int lane = lane_id(), wave = wave_uniform();
   dcx* z = buf[wave];
-  const int ob = wave_out_base_d();
+  const int os = wave_out_slot_base_d();
+  const int c0 = lane == 0 ? 2 : 0;                               // zslot(1024 - k), k = lane + 64 j: 1024 - k + 2 (15 - j) + c0
   const int64_t ngroups = (P.nframes + 3) / 4;
   float2 vf[16];                                                   // the next frame's samples, in flight while this one is transformed
   if (4 * (int64_t)blockIdx.x + wave < P.nframes) load_frame_raw(x, (4 * (int64_t)blockIdx.x + wave) * kHop, vf);
@@ -773,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     const dcx* twf = reload_each_tile(twd);                       // tables re-read per frame, not hoisted into ~200 registers
     int toff = 0;
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
-    const WaveTwD T{ tws + toff + kTwq, tws + toff };
+    const WaveTwD T{ tws + toff + kTwqLds, tws + toff };
     const dcx wl = twf[kTwl + kTwq + lane];                        // W2048^lane
     const WinSrc<SYM> Wn{ reload_each_tile(wing), winh + toff };
     window_frame_d(vf, Wn, pre_gain, v);
@@ -784,17 +798,17 @@ __global__ __launch_bounds__(256, 2) void k_dh_bands_x(const float* __restrict__
     wave_sync();
     fft1024_wave_d<false>(v, z, T);
 #pragma unroll
-    for (int j = 0; j < 16; j++) z[wave_out_index_d(ob, j)] = v[j];
+    for (int j = 0; j < 16; j++) z[wave_out_slot_d(os, j)] = v[j];
     wave_sync();
     float* mg = mags_out + (chan * P.nframes + f) * kBins;         // magnitudes[bin], a Float32Array (:456-460): 256-byte runs per store
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = lane + 64 * j;
       if (k == 0) {
-        const dcx z0 = z[0], zh = z[512];
+        const dcx z0 = z[0], zh = z[zslot(512)];
         mg[0] = f32r(fabs(z0.x + z0.y)); mg[512] = mag_f32(zh);        // X[0] = Re + Im of Z[0] (real); bin 512 = conj Z[512]
       } else {
-        const BinPairD p = split_pair_d(z[k], z[kM - k], tw2048_lane_j(wl, j));
+        const BinPairD p = split_pair_d(z[k + 2 * j], z[kM - k + 2 * (15 - j) + c0], tw2048_lane_j(wl, j));
         mg[k] = mag_f32(dcx{ p.xe.x + p.t.x, p.xe.y + p.t.y });
         mg[kM - k] = mag_f32(dcx{ p.xe.x - p.t.x, p.xe.y - p.t.y });
       }
@@ -838,7 +852,8 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
   int64_t f1 = f0 + seg_frames; if (f1 > F) f1 = F;
   const int64_t fs = f0 - warm > 0 ? f0 - warm : 0;
   const bool last_seg = f1 >= F;
-  const int ob = wave_out_base_d();
+  const int ob = wave_out_base_d(), os = wave_out_slot_base_d();
+  const int c0 = lane == 0 ? 2 : 0;                               // zslot(1024 - k), k = lane + 64 j: 1024 - k + 2 (15 - j) + c0
   dcx* zw = buf[wave];
   float* bg = bgs[wave];
   double* bl = bls[wave];
@@ -862,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     const dcx* twf = reload_each_tile(twd);
     int toff = 0;
     asm volatile("" : "+s"(toff));                                 // same for the LDS tables (an opaque offset keeps them ds_reads)
-    WaveTwD T{ tws + toff + kTwq, tws + toff };
+    WaveTwD T{ tws + toff + kTwqLds, tws + toff };
 
     WinSrc<SYM> Wn{ reload_each_tile(wing), winh + toff };
     {                                                              // (loads a frame ahead cost this kernel 32 registers it does not have)
@@ -878,7 +893,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
     wave_sync();
     fft1024_wave_d<false>(v, zw, T);
 #pragma unroll
-    for (int j = 0; j < 16; j++) zw[wave_out_index_d(ob, j)] = v[j];
+    for (int j = 0; j < 16; j++) zw[wave_out_slot_d(os, j)] = v[j];
     wave_sync();
     // ResonanceDetector.analyze (:194-233) and the gain of one bin (:361-382), with the reference's Float32Array stores
     auto bin_gain = [&](float mag, float& av_state, int band, int bin) -> double {
@@ -911,17 +926,18 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       const int k = lane + 64 * j;
       const int bk = (int)(bands >> (3 * j)) & 7, bm = (int)(bands >> (24 + 3 * j)) & 7;
       if (j == 0 && k == 0) {
-        const dcx z0 = zw[0], zh = zw[512];
+        const dcx z0 = zw[0], zh = zw[zslot(512)];
         const double x0 = z0.x + z0.y, xny = z0.x - z0.y;         // X[0] and X[1024] are real; the Nyquist bin is not scaled
         const double g0 = bin_gain(f32r(fabs(x0)), avg[0], bk, 0);
         const double gh = bin_gain(mag_f32(zh), avg[1], bm, 512);
         if (synth) {
           const double y0 = x0 * g0;
           zw[0] = dcx{ 0.5 * (y0 + xny), 0.5 * (y0 - xny) };
-          zw[512] = dcx{ zh.x * gh, zh.y * gh };
+          zw[zslot(512)] = dcx{ zh.x * gh, zh.y * gh };
         }
       } else {
-        const dcx zk = zw[k], zm = zw[kM - k];
+        const int sk = k + 2 * j, sm = kM - k + 2 * (15 - j) + c0;       // zslot(k), zslot(1024 - k)
+        const dcx zk = zw[sk], zm = zw[sm];
         const dcx wtw = tw2048_lane_j(wl, j);
         const BinPairD p = split_pair_d(zk, zm, wtw);
         const dcx xk{ p.xe.x + p.t.x, p.xe.y + p.t.y }, xmc{ p.xe.x - p.t.x, p.xe.y - p.t.y };
@@ -931,18 +947,18 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
           const dcx yk{ xk.x * gk, xk.y * gk }, ymc{ xmc.x * gm, xmc.y * gm };
           const dcx ye{ 0.5 * (yk.x + ymc.x), 0.5 * (yk.y + ymc.y) };
           const dcx yo = dmulc(dcx{ 0.5 * (yk.x - ymc.x), 0.5 * (yk.y - ymc.y) }, wtw);
-          zw[k] = dcx{ ye.x - yo.y, ye.y + yo.x };
-          zw[kM - k] = dcx{ ye.x + yo.y, yo.x - ye.y };
+          zw[sk] = dcx{ ye.x - yo.y, ye.y + yo.x };
+          zw[sm] = dcx{ ye.x + yo.y, yo.x - ye.y };
         }
       }
     }
     if (!synth) continue;                                          // a warm-up frame: analysis only
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = zw[64 * r + lane];
+    for (int r = 0; r < 16; r++) v[r] = zw[66 * r + lane];      // zslot(64 r + lane)
     twf = reload_each_tile(twf);
     asm volatile("" : "+s"(toff));
-    T = WaveTwD{ tws + toff + kTwq, tws + toff };
+    T = WaveTwD{ tws + toff + kTwqLds, tws + toff };
     fft1024_wave_d<true>(v, zw, T);
     Wn = WinSrc<SYM>{ reload_each_tile(wing), winh + toff };
     wave_sync();                                                   // the exchange's reads precede the float writes below (other layout)
@@ -953,7 +969,9 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       // outputBuffer[i] = inverseBuffer[2 i] * window[i], a Float32Array (fft.js:63-65); inverse includes 1 / N
       // m = ob + 16 (j & 3) + 256 (j >> 2) with ob + 16 (j & 3) < 256: the half of the table is known from j alone
       const float2 ws = j < 8 ? window_pair<true, SYM>(Wn, m) : window_pair<false, SYM>(Wn, m);   // the inverse's 1 / N is an exact scaling: applied to the window
-      yf[m] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
+      // pair m at float2 slot m + 4 (m >> 6) (m >> 6 = q + 4 (j >> 2)): sixteen contiguous lanes - four a, four q - then store to
+      // sixteen different slots of the 128-byte row ds_write_b64 banks over, not to four
+      yf[m + 4 * (lane & 3) + 16 * (j >> 2)] = make_float2(f32r(v[j].x * (double)(ws.x * (1.0f / kM))), f32r(v[j].y * (double)(ws.y * (1.0f / kM))));
     }
     wave_sync();
     const float* yw = (const float*)zw;
@@ -968,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void k_dh_apply_x(const float* __restrict__
       for (int jj = 0; jj < 8; jj++) dryv[jj] = load_in(pos + lane + 64 * jj);
     }
 #pragma unroll
-    for (int j = 0; j < 32; j++) acc[j] += yw[(lane + 64 * j - rot) & (kN - 1)];
+    for (int j = 0; j < 32; j++) { const int i = (lane + 64 * j - rot) & (kN - 1); acc[j] += yw[i + 8 * (i >> 7)]; }   // (float i of the frame at i + 8 (i >> 7))
 #define WAM_DH_FINISH(G)                                                                              \
     _Pragma("unroll") for (int jj = 0; jj < 8; jj++) {                                                \
       if (emit) {                                                                                     \
