@@ -49,6 +49,18 @@ def test_deharsh_segments(hot, exact):
         assert maxerr(y, whole) <= SEAM_TOL
 
 
+@pytest.mark.parametrize("preset", ["mastering", "aggressive"])
+def test_deharsh_window_from_global_memory_is_bit_identical(hot, preset):
+    """The default de-harsh kernels are compiled twice: with the first half of the Hann table in LDS (it mirrors in f32 with this libm's
+    cos) and with the table read from global memory (a host whose table does not mirror).  Same numbers either way."""
+    sr, x = hot
+    want = wam.process_hybrid_dynamic(x, sr, preset)
+    wam.tune("dh_win_lds", 0)
+    got = wam.process_hybrid_dynamic(x, sr, preset)
+    for a, b in zip(got, want):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_soft_clip_segments(hot):
     sr, x = hot
     ref = O.soft_clip(x, sr, -1.0, 0.5, 10.0, 1.5)

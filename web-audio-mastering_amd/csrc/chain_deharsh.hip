@@ -1070,6 +1070,7 @@ int enqueue_deharsh(const float* in, float* out, int ntracks, int nch, int64_t n
   for (int i = 0; i < kN; i++) win[i] = (float)(0.5 * (1 - std::cos(2 * M_PI * i / (kN - 1))));     // utils.js:98-104
   int win_sym = 1;                                                // the exact kernels keep half the table in LDS if it mirrors (it does with glibc's cos)
   for (int i = 0; i < kN / 2; i++) if (win[i] != win[kN - 1 - i]) win_sym = 0;
+  if (!tuning().dh_win_lds) win_sym = 0;
   WAM_HIP(hipMemcpyAsync(plan.p, &dp, sizeof(dp), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(twb.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, s));
   WAM_HIP(hipMemcpyAsync(winb.p, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice, s));
