@@ -59,13 +59,18 @@ TIME_ASM(k_cmp32, F8, asm volatile("v_cmp_gt_f32 vcc, %0, %8\nv_cmp_gt_f32 vcc, 
 TIME_ASM(k_fma32, F8, ASM_F("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8"))
 TIME_ASM(k_rcp32, F8, ASM_F("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7"))
 
+#define G8F float g0 = 1, g1 = 2, g2 = 3, g3 = 4, g4 = 5, g5 = 6, g6 = 7, g7 = 8
+TIME_ASM(k_sel2_vcc, F8; G8F, asm volatile("v_cmp_gt_f32 vcc, %0, %16\n v_cndmask_b32 %0, %0, %16, vcc\n v_cndmask_b32 %8, %8, %16, vcc\nv_cmp_gt_f32 vcc, %1, %16\n v_cndmask_b32 %1, %1, %16, vcc\n v_cndmask_b32 %9, %9, %16, vcc\nv_cmp_gt_f32 vcc, %2, %16\n v_cndmask_b32 %2, %2, %16, vcc\n v_cndmask_b32 %10, %10, %16, vcc\nv_cmp_gt_f32 vcc, %3, %16\n v_cndmask_b32 %3, %3, %16, vcc\n v_cndmask_b32 %11, %11, %16, vcc\nv_cmp_gt_f32 vcc, %4, %16\n v_cndmask_b32 %4, %4, %16, vcc\n v_cndmask_b32 %12, %12, %16, vcc\nv_cmp_gt_f32 vcc, %5, %16\n v_cndmask_b32 %5, %5, %16, vcc\n v_cndmask_b32 %13, %13, %16, vcc\nv_cmp_gt_f32 vcc, %6, %16\n v_cndmask_b32 %6, %6, %16, vcc\n v_cndmask_b32 %14, %14, %16, vcc\nv_cmp_gt_f32 vcc, %7, %16\n v_cndmask_b32 %7, %7, %16, vcc\n v_cndmask_b32 %15, %15, %16, vcc\n" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7) : "v"(cf) : "vcc"); f0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+TIME_ASM(k_sel2_sgpr, F8; G8F, asm volatile("v_cmp_gt_f32_e64 s[10:11], %0, %16\n v_cndmask_b32_e64 %0, %0, %16, s[10:11]\n v_cndmask_b32_e64 %8, %8, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %1, %16\n v_cndmask_b32_e64 %1, %1, %16, s[10:11]\n v_cndmask_b32_e64 %9, %9, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %2, %16\n v_cndmask_b32_e64 %2, %2, %16, s[10:11]\n v_cndmask_b32_e64 %10, %10, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %3, %16\n v_cndmask_b32_e64 %3, %3, %16, s[10:11]\n v_cndmask_b32_e64 %11, %11, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %4, %16\n v_cndmask_b32_e64 %4, %4, %16, s[10:11]\n v_cndmask_b32_e64 %12, %12, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %5, %16\n v_cndmask_b32_e64 %5, %5, %16, s[10:11]\n v_cndmask_b32_e64 %13, %13, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %6, %16\n v_cndmask_b32_e64 %6, %6, %16, s[10:11]\n v_cndmask_b32_e64 %14, %14, %16, s[10:11]\nv_cmp_gt_f32_e64 s[10:11], %7, %16\n v_cndmask_b32_e64 %7, %7, %16, s[10:11]\n v_cndmask_b32_e64 %15, %15, %16, s[10:11]\n" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7) : "v"(cf) : "s10", "s11"); f0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+TIME_ASM(k_sel_gap_vcc, F8; G8F, asm volatile("v_cmp_gt_f32 vcc, %0, %16\n v_add_f32 %8, %8, %16\n v_cndmask_b32 %0, %0, %16, vcc\nv_cmp_gt_f32 vcc, %1, %16\n v_add_f32 %9, %9, %16\n v_cndmask_b32 %1, %1, %16, vcc\nv_cmp_gt_f32 vcc, %2, %16\n v_add_f32 %10, %10, %16\n v_cndmask_b32 %2, %2, %16, vcc\nv_cmp_gt_f32 vcc, %3, %16\n v_add_f32 %11, %11, %16\n v_cndmask_b32 %3, %3, %16, vcc\nv_cmp_gt_f32 vcc, %4, %16\n v_add_f32 %12, %12, %16\n v_cndmask_b32 %4, %4, %16, vcc\nv_cmp_gt_f32 vcc, %5, %16\n v_add_f32 %13, %13, %16\n v_cndmask_b32 %5, %5, %16, vcc\nv_cmp_gt_f32 vcc, %6, %16\n v_add_f32 %14, %14, %16\n v_cndmask_b32 %6, %6, %16, vcc\nv_cmp_gt_f32 vcc, %7, %16\n v_add_f32 %15, %15, %16\n v_cndmask_b32 %7, %7, %16, vcc\n" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7) : "v"(cf) : "vcc"); f0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
 int main() {
   long long* out; hipMallocManaged(&out, 8 * 2048);
   struct { const char* name; void (*k)(long long*, double); int per; } ks[] = {
     {"v_fma_f64", k_fma64, 8}, {"v_mul_f64", k_mul64, 8}, {"v_add_f64", k_add64, 8}, {"v_max_f64", k_max64, 8}, {"v_cmp_gt_f64", k_cmp64, 8},
     {"v_rcp_f64", k_rcp64, 8}, {"v_rsq_f64", k_rsq64, 8}, {"v_rndne_f64", k_rndne64, 8}, {"v_ldexp_f64", k_ldexp64, 8},
     {"v_cvt f64->f32->f64 (pair)", k_cvt, 16}, {"v_cvt_f32_f64", k_cvt_to32, 8}, {"v_mov_b32_dpp", k_movdpp, 8}, {"v_mov_b32", k_mov32, 8},
-    {"v_cndmask_b32", k_cndmask, 8}, {"v_cndmask_b32_e64 sgpr", k_cndmask_sgpr, 8}, {"v_cndmask_b32 indep dst (+1 add)", k_cndmask_indep, 8}, {"v_max_f32", k_max32, 8}, {"cmp + cndmask via vcc", k_cmpsel_vcc, 16}, {"cmp + cndmask via sgpr pair", k_cmpsel_sgpr, 16}, {"v_cmp_gt_f32 vcc", k_cmp32, 8}, {"v_fma_f32", k_fma32, 8}, {"v_rcp_f32", k_rcp32, 8} };
+    {"v_cndmask_b32", k_cndmask, 8}, {"v_cndmask_b32_e64 sgpr", k_cndmask_sgpr, 8}, {"v_cndmask_b32 indep dst (+1 add)", k_cndmask_indep, 8}, {"v_max_f32", k_max32, 8}, {"cmp + cndmask via vcc", k_cmpsel_vcc, 16}, {"cmp + cndmask via sgpr pair", k_cmpsel_sgpr, 16}, {"v_cmp_gt_f32 vcc", k_cmp32, 8}, {"v_fma_f32", k_fma32, 8}, {"v_rcp_f32", k_rcp32, 8},
+    {"cmp + 2 cndmask via vcc (64-bit select)", k_sel2_vcc, 24}, {"cmp + 2 cndmask via sgpr pair", k_sel2_sgpr, 24}, {"cmp, add, cndmask via vcc", k_sel_gap_vcc, 24} };
   for (auto& e : ks) {
     for (int waves = 1; waves <= 4; waves *= 2) {         // 1, 2 or 4 wavefronts per SIMD on one CU (256 / 512 / 1024 threads)
       hipLaunchKernelGGL(e.k, dim3(1), dim3(256 * waves), 0, 0, out, 1.25); hipDeviceSynchronize();
