@@ -8,7 +8,9 @@ output of ONE track rendered through wam_render_chain with the oracle's render o
 
   (a) the 180 s / 48 kHz track at the C2 settings (BASELINE configs[1]);
   (b) the same track hard-driven (+6 dB input, -9 LUFS target, -0.3 dB ceiling): the clipper's worst case;
-  (c) 5 min 20 s at 96 kHz stereo with a nearly silent minute (configs[3]'s shape: rate-scaled warm-ups, both gates act).
+  (c) 5 min 20 s at 96 kHz stereo with a nearly silent minute (configs[3]'s shape: rate-scaled warm-ups, both gates act);
+  (d) 200 s at 44.1 kHz, hard-driven: hops and warmth windows of 4,410 samples (not multiples of a 16-sample chunk), the
+      exciter's fused window peaks on their general path.
 
 Bar: 1e-5 max abs on PCM (north_star).  The assertion message carries max |d| and the count of samples above 1e-6.
 """
@@ -27,6 +29,7 @@ HOT = dict(C2, inputGain=6, targetLufs=-9, truePeakCeiling=-0.3)
 CASES = {
     "c2_180s_48k": (48000, 48000 * 180, C2, {"amp": 1.6, "clickAmp": 0.6}),
     "hot_180s_48k": (48000, 48000 * 180, HOT, {"amp": 1.6, "clickAmp": 0.6}),
+    "hot_200s_44k": (44100, 44100 * 200, HOT, {"amp": 1.8, "clickAmp": 0.7}),
     "quiet_320s_96k": (96000, 96000 * 320, C2, {"amp": 1.6, "clickAmp": 0.6, "quietFrom": 96000 * 100, "quietTo": 96000 * 160, "quietGain": 0.003}),
 }
 
