@@ -212,31 +212,44 @@ __global__ __launch_bounds__(256) void k_pcm16(const float* __restrict__ in, int
 // ------------------------------------------------------------------ spectrogram STFT
 struct StftRow { int bin1, bin2; double frac; int valid; };
 
-// 10 log10(pw + 1e-24) + add_db, floored at -144 (spectrogram.js:135-141), for pw >= 0 finite.  ln by the mantissa's atanh series
-// (m in [sqrt(1/2), sqrt(2)): s = (m - 1) / (m + 1), |s| <= 0.172, odd series to s^17: truncation 2e-15 relative), ~30 instructions
-// against ~90 for ocml's log10; the result is an f32 store, and all three STFT kernels share this function (they must agree to the bit).
-__device__ __forceinline__ float stft_db(double pw, double add_db) {
+// 10 log10(pw + 1e-24) + add_db, floored at -144 (spectrogram.js:135-141), for pw >= 0 finite.  x = 2^E m, m in [0.5, 1); the top
+// five mantissa bits pick one of 32 intervals with centre c, the table holds (1 / c, 10 log10 c) - the second for the double that
+// 1 / c actually is, from the host's long double log10 - and r = m (1 / c) - 1 (one FMA, |r| <= 1 / 64) goes through the series of
+// 10 log10(1 + r) to r^8 (truncation 6e-18 in the natural log): ~22 instructions against ~33 for a division and an atanh series
+// and ~90 for ocml's log10.  The result is an f32 store, and all three STFT kernels share this function (they must agree to the bit).
+constexpr int kLogTab = 32;
+#ifndef WAM_STFT_DB_GROUP
+#define WAM_STFT_DB_GROUP 4
+#endif
+// (in two halves, so that a kernel with nothing else to hide the table read's latency can start the next value's read first)
+struct StftDbHead { double m; int E; double2 t; };
+__device__ __forceinline__ StftDbHead stft_db_head(double pw, const double2* __restrict__ lt) {
   const double x = pw + 1e-24;
-  double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
-  int E = __builtin_amdgcn_frexp_exp(x);
-  if (m < 0.70710678118654752) { m *= 2.0; E -= 1; }
-  const double sq = div_fast(m - 1.0, m + 1.0), s2 = sq * sq;
-  double p = 1.0 / 17.0;
-  p = fma(p, s2, 1.0 / 15.0);
-  p = fma(p, s2, 1.0 / 13.0);
-  p = fma(p, s2, 1.0 / 11.0);
-  p = fma(p, s2, 1.0 / 9.0);
-  p = fma(p, s2, 1.0 / 7.0);
-  p = fma(p, s2, 1.0 / 5.0);
-  p = fma(p, s2, 1.0 / 3.0);
-  p = fma(p, s2, 1.0);
-  // 10 log10(x) = E 10 log10(2) + (20 / ln 10) s p
-  const double db = fma((double)E, 3.01029995663981195214, 8.68588963806503655303 * sq * p) + add_db;
+  StftDbHead h;
+  h.m = __builtin_amdgcn_frexp_mant(x);                   // [0.5, 1)
+  h.E = __builtin_amdgcn_frexp_exp(x);
+  h.t = lt[(__double2hiint(h.m) >> 15) & (kLogTab - 1)];
+  return h;
+}
+__device__ __forceinline__ float stft_db_tail(const StftDbHead& h, double add_db) {
+  const double r = fma(h.m, h.t.x, -1.0);
+  constexpr double K = 4.34294481903251827651;            // 10 / ln 10
+  double q = -K / 8;
+  q = fma(q, r, K / 7);
+  q = fma(q, r, -K / 6);
+  q = fma(q, r, K / 5);
+  q = fma(q, r, -K / 4);
+  q = fma(q, r, K / 3);
+  q = fma(q, r, -K / 2);
+  q = fma(q, r, K);
+  const double db = fma((double)h.E, 3.01029995663981195214, fma(r, q, h.t.y)) + add_db;
   return f32r(db < -144 ? -144.0 : db);
 }
+__device__ __forceinline__ float stft_db(double pw, double add_db, const double2* __restrict__ lt) { return stft_db_tail(stft_db_head(pw, lt), add_db); }
 __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int nch, int64_t n, int nfft, int bits, int hop, int64_t nframes,
                                               const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
-                                              double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols) {
+                                              double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols,
+                                              const double2* __restrict__ logt) {
   extern __shared__ float sm[];
   float* re = sm; float* im = sm + nfft; float* sp = sm + 2 * nfft;
   const int half = nfft >> 1;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(256) void k_stft(const float* __restrict__ in, int 
     }
     for (int i = threadIdx.x; i < half; i += 256) {
       const double pw = (double)re[i] * (double)re[i] + (double)im[i] * (double)im[i];
-      const float v = stft_db(pw, add_db);                            // spectrogram.js:135-141
+      const float v = stft_db(pw, add_db, logt);                      // spectrogram.js:135-141
       sp[i] = v;
       out_db[f * half + i] = v;
     }
@@ -320,7 +333,8 @@ __device__ __forceinline__ void stft_stages(float2 v[R], int logD, int low, cons
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in, int nch, int64_t n, int hop, int64_t nframes,
                                                    const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
-                                                   double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols) {
+                                                   double add_db, float* __restrict__ out_db, const StftRow* __restrict__ rows, float* __restrict__ cols,
+                                                   const double2* __restrict__ logt) {
   constexpr int N = 1 << LOGN, PT = N / 256, LP = LOGN - 8, half = N / 2;
   __shared__ float2 z[N + N / 16];
   __shared__ float2 tw[N / 2];
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(256) void k_stft_fast(const float* __restrict__ in,
       for (int m = 0; m < RL / 2; m++) {               // bins below N / 2
         const int i = u + m * (N / RL);
         const double pw = (double)w4[m].x * (double)w4[m].x + (double)w4[m].y * (double)w4[m].y;
-        const float o = stft_db(pw, add_db);                            // spectrogram.js:135-141
+        const float o = stft_db(pw, add_db, logt);                      // spectrogram.js:135-141
         sp[i] = o;
         out_db[f * half + i] = o;
       }
@@ -440,40 +454,28 @@ __device__ __forceinline__ void stft_local_stage(float re[64], float im[64], con
   }
 }
 // stage 7 + J on positions lane + 64 m: butterfly (m, m + 2^J) has k = lane + 64 (m mod 2^J), table stride 2^(5 - J).
-// Thirty-two butterflies, four at a time between scheduling fences: butterfly b has t = b mod h, m = 2 h (b div h) + t; the four
-// twiddle reads of a group go out together at its start (one LDS round trip per group, not one per butterfly in the last stages).
-#ifndef WAM_STFT_GROUP_FROM
-#define WAM_STFT_GROUP_FROM 6
-#endif
+// Thirty-two butterflies in twiddle-major order (t = m mod h outer), eight at a time between scheduling fences; the twiddles of
+// the NEXT eight are read from LDS before these eight are computed.  With one wavefront per SIMD nothing else covers an LDS
+// round trip: read where they are used, the stage-12 twiddles alone (one per butterfly) exposed thirty-two of them per frame.
 template <int J>
 __device__ __forceinline__ void stft_cross_stage(float re[64], float im[64], const float2* twl, int lane) {
-  constexpr int h = 1 << J;
-  if constexpr (J < WAM_STFT_GROUP_FROM) {               // few twiddles: one read per twiddle, its butterflies four at a time
+  constexpr int h = 1 << J, per_t = 32 / h;              // butterflies per twiddle
+  constexpr int GB = 8, NG = 32 / GB;                    // butterflies per group, groups
+  constexpr int TW = per_t >= GB ? 1 : GB / per_t;       // twiddles per group: 1, 1, 1, 2, 4, 8
+  float2 cur[TW], nxt[TW];
+  auto fetch = [&](int g, float2 w[TW]) {
 #pragma unroll
-    for (int t = 0; t < h; t++) {
-      const float2 wf = twl[(lane + 64 * t) << (5 - J)];
-      const double cw = wf.x, sw = wf.y;
-      int done = 0;
+    for (int i = 0; i < TW; i++) w[i] = twl[(lane + 64 * ((g * GB) / per_t + i)) << (5 - J)];
+  };
+  fetch(0, cur);
 #pragma unroll
-      for (int m = t; m < 64; m += 2 * h) {
-        if ((done++ & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-        const double xr = re[m + h], xi = im[m + h];
-        const double tr = xr * cw - xi * sw;
-        const double ti = xr * sw + xi * cw;
-        const double ar = re[m], ai = im[m];
-        re[m + h] = f32r(ar - tr); im[m + h] = f32r(ai - ti);
-        re[m] = f32r(ar + tr); im[m] = f32r(ai + ti);
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int g = 0; g < 8; g++) {
+  for (int g = 0; g < NG; g++) {
     __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < NG) fetch(g + 1, nxt);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int b = 4 * g + q, t = b % h, m = 2 * h * (b / h) + t;
-      const float2 wf = twl[(lane + 64 * t) << (5 - J)];
+    for (int q = 0; q < GB; q++) {
+      const int b = g * GB + q, t = b / per_t, m = t + 2 * h * (b % per_t);
+      const float2 wf = cur[t - (g * GB) / per_t];
       const double cw = wf.x, sw = wf.y;
       const double xr = re[m + h], xi = im[m + h];
       const double tr = xr * cw - xi * sw;
@@ -482,17 +484,23 @@ __device__ __forceinline__ void stft_cross_stage(float re[64], float im[64], con
       re[m + h] = f32r(ar - tr); im[m + h] = f32r(ai - ti);
       re[m] = f32r(ar + tr); im[m] = f32r(ai + ti);
     }
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < TW; i++) cur[i] = nxt[i];
+    }
   }
 }
 template <int NCHT, bool COLS>
 __global__ __launch_bounds__(64 * kSwWaves) void k_stft_wave(const float* __restrict__ in, int64_t n, int hop, int64_t nframes,
                                                              const float* __restrict__ cosT, const float* __restrict__ sinT, const float* __restrict__ win,
                                                              const double2* __restrict__ tw6, double add_db, float* __restrict__ out_db,
-                                                             const StftRow* __restrict__ rows, float* __restrict__ cols) {
+                                                             const StftRow* __restrict__ rows, float* __restrict__ cols, const double2* __restrict__ logt) {
 #pragma clang fp contract(off)       // (see stft_local_stage; the double butterflies' products are exact, fused or not)
   __shared__ float2 twl[kSwN / 2];
   __shared__ float winl[kSwN];
   __shared__ float exch[kSwWaves][kSwPad];
+  __shared__ double2 logl[kLogTab];
+  if (threadIdx.x < kLogTab) logl[threadIdx.x] = logt[threadIdx.x];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (int i = threadIdx.x; i < kSwN / 2; i += 64 * kSwWaves) twl[i] = make_float2(cosT[i], sinT[i]);
   for (int i = threadIdx.x; i < kSwN; i += 64 * kSwWaves) winl[i] = win[i];
@@ -537,6 +545,7 @@ __global__ __launch_bounds__(64 * kSwWaves) void k_stft_wave(const float* __rest
     const float* winf = winl + zero;
     const double2* tw6f = tw6 + zero;
     const float2* twlf = twl + zero;
+    const double2* logf = logl + zero;
     float re[64], im[64];
     // position 64 lane + m of the bit-reversed array holds sample brev12(64 lane + m) = 64 brev6(m) + brev6(lane)  (spectrogram.js:121-123, :222-235)
 #pragma unroll
@@ -585,13 +594,31 @@ __global__ __launch_bounds__(64 * kSwWaves) void k_stft_wave(const float* __rest
       }
     }
     if (COLS) stft_wave_sync();                          // the reads of buf above precede the writes below
+    // bins lane + 64 m < 2048, in groups of four: the table reads of the next group are issued before this group's polynomials
+    // (one wavefront per SIMD: nothing else would cover their latency)
+    constexpr int G = WAM_STFT_DB_GROUP;
+    StftDbHead hd[G];
 #pragma unroll
-    for (int m = 0; m < 32; m++) {                       // bins lane + 64 m < 2048
-      if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-      const double pw = (double)re[m] * (double)re[m] + (double)im[m] * (double)im[m];
-      const float v = stft_db(pw, add_db);
-      o[64 * m] = v;
-      if (COLS) buf[lo + 64 * m] = v;
+    for (int i = 0; i < G; i++) hd[i] = stft_db_head((double)re[i] * (double)re[i] + (double)im[i] * (double)im[i], logf);
+#pragma unroll
+    for (int g = 0; g < 32 / G; g++) {
+      __builtin_amdgcn_sched_barrier(0);
+      StftDbHead nx[G];
+      if (g + 1 < 32 / G) {
+#pragma unroll
+        for (int i = 0; i < G; i++) { const int m = G * (g + 1) + i; nx[i] = stft_db_head((double)re[m] * (double)re[m] + (double)im[m] * (double)im[m], logf); }
+      }
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        const int m = G * g + i;
+        const float v = stft_db_tail(hd[i], add_db);
+        o[64 * m] = v;
+        if (COLS) buf[lo + 64 * m] = v;
+      }
+      if (g + 1 < 32 / G) {
+#pragma unroll
+        for (int i = 0; i < G; i++) hd[i] = nx[i];
+      }
     }
     if (COLS) {
       stft_wave_sync();
@@ -971,6 +998,19 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
   if (ntracks >= 64 && bx > 128) bx = 128;                               // enough workgroups from the track dimension
   const size_t shmem = sizeof(float) * (size_t)(2 * nfft + half);
   const float* ct = tabs.as<float>(); const float* st = ct + nfft; const float* wn = ct + 2 * nfft;
+  // stft_db's table: 32 intervals of the mantissa, (1 / c, 10 log10 c) with the logarithm taken of the double 1 / c itself
+  DevBuf logtb;
+  {
+    double lt[2 * kLogTab];
+    for (int i = 0; i < kLogTab; i++) {
+      const double c = 0.5 + (i + 0.5) / (2.0 * kLogTab), rcp = 1.0 / c;
+      lt[2 * i] = rcp; lt[2 * i + 1] = (double)(-10.0L * log10l((long double)rcp));
+    }
+    rc = logtb.alloc(sizeof(lt)); if (rc) return rc;
+    WAM_HIP(hipMemcpyAsync(logtb.p, lt, sizeof(lt), hipMemcpyHostToDevice, stream));
+    WAM_HIP(hipStreamSynchronize(stream));                               // lt is a local
+  }
+  const double2* logt = (const double2*)logtb.as<double2>();
   DevBuf tw6b;
   if (nfft == 4096) {                                                    // stages 1-6 of the wavefront kernel: (cos, sin)[64 k], k < 32, widened
     std::vector<double> t6(64);
@@ -986,19 +1026,19 @@ static int stft_enqueue(const float* in_dev, int ntracks, int nch, int64_t n, do
     if (gx > 64) gx = 64;
     if (ntracks < 64) { const int64_t want = (2048 + ntracks - 1) / ntracks; gx = (nframes + kSwWaves - 1) / kSwWaves; if (gx > want) gx = want; }
 #define WAM_STFT_WAVE(NC, CL) hipLaunchKernelGGL((k_stft_wave<NC, CL>), dim3((unsigned)gx, (unsigned)ntracks), dim3(64 * kSwWaves), 0, stream, in_dev, n, hop, nframes, \
-                                                 ct, st, wn, (const double2*)tw6b.as<double2>(), add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev)
+                                                 ct, st, wn, (const double2*)tw6b.as<double2>(), add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev, logt)
     if (nch == 2) { if (cols_dev) WAM_STFT_WAVE(2, true); else WAM_STFT_WAVE(2, false); }
     else { if (cols_dev) WAM_STFT_WAVE(1, true); else WAM_STFT_WAVE(1, false); }
 #undef WAM_STFT_WAVE
   } else if (nfft == 4096 && variant != 1)
     hipLaunchKernelGGL(k_stft_fast<12>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
-                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev, logt);
   else if (nfft == 2048 && variant != 1)
     hipLaunchKernelGGL(k_stft_fast<11>, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), 0, stream, in_dev, nch, n, hop, nframes, ct, st, wn, add_db,
-                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+                       out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev, logt);
   else
     hipLaunchKernelGGL(k_stft, dim3((unsigned)bx, (unsigned)ntracks), dim3(256), shmem, stream, in_dev, nch, n, nfft, bits, hop, nframes, ct, st, wn,
-                       add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev);
+                       add_db, out_db_dev, (const StftRow*)rowsd.as<StftRow>(), cols_dev, logt);
   prof_end(prof_ticket, stream);
   WAM_HIP(hipGetLastError());
   WAM_HIP(hipStreamSynchronize(stream));                                 // tables (host vectors, pool blocks) are released on return
