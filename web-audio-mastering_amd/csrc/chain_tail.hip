@@ -237,6 +237,13 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   const int64_t T0 = (int64_t)blockIdx.x * seg_tiles;
   int64_t T1 = T0 + seg_tiles; if (T1 > ntiles) T1 = ntiles;
   const int64_t Tw = T0 - warm > 0 ? T0 - warm : 0;
+  // the next tile's samples are requested before this tile is computed; nothing else is loaded inside the loop (k_exciter)
+  float nv[NCH][C];
+  auto fetch = [&](int64_t t) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) load_chunk(in + (trk * NCH + c) * n, n, t * kTile + (int64_t)threadIdx.x * C, nv[c]);
+  };
+  fetch(Tw);
   for (int64_t t = Tw; t < T1; t++) {
     const int64_t tile_base = t * kTile;
     const int64_t base = tile_base + (int64_t)threadIdx.x * C;
@@ -245,11 +252,10 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
     for (int k = 0; k < C; k++) { q[k] = 0; pk[k] = 0; }
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      float v[C];
-      load_chunk(in + (trk * NCH + c) * n, n, base, v);
 #pragma unroll
-      for (int k = 0; k < C; k++) { const double d = v[k]; q[k] += d * d; pk[k] = fmax(pk[k], fabs(d)); }
+      for (int k = 0; k < C; k++) { const double d = nv[c][k]; q[k] += d * d; pk[k] = fmax(pk[k], fabs(d)); }
     }
+    if (t + 1 < T1) fetch(t + 1);
     double run = 0;
 #pragma unroll
     for (int k = 0; k < C; k++) { q[k] /= NCH; run += q[k]; q[k] = run; }       // local inclusive prefix
