@@ -318,6 +318,9 @@ __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict_
   const float* src = band_rms + (int64_t)chan * F * kBands + b;
   double* dst = env + (int64_t)chan * F * kBands + b;
   LdsSlots slots(lds_scan);
+  __shared__ double flT[C + 2];                                   // follower_al_table of this band's follower
+  follower_al_table(A, R, flT);
+  lds_barrier();
   double Senv = 0;
   const int64_t ntiles = (F + kTile - 1) / kTile;
   float nx[C];
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_dh_follow(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < C; k++) a[k] = nx[k];
     if (t + 1 < ntiles) fetch(t + 1);
-    double e = follower_solve(a, A, R, Senv, slots.next());
+    double e = follower_solve(a, A, R, Senv, flT, slots.next());
 #pragma unroll
     for (int k = 0; k < C; k++) {
       e = follower_step(e, (double)a[k], A, R);

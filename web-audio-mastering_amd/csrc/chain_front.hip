@@ -50,6 +50,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
   // (thread 0 stores after the scan, everybody reads at the next tile) and not in six VGPRs per thread
   __shared__ double Scar[NCH + 1];
   if (threadIdx.x <= NCH) Scar[threadIdx.x] = 0;
+  __shared__ double glT[C + 2];                   // follower_al_table of the glue follower
+  follower_al_table(fp->glue_A, fp->glue_R, glT);
   MeterStateL ms[NCH];
   if (do_meter) for (int c = 0; c < NCH; c++) meter_init_l(ms[c], *mp, sg.Tw * kTile, sg, &Pl[kFShelf][0][0], &Pl[kFKhp][0][0], Sl[c * 9 + 7], Sl[c * 9 + 8]);
   lds_barrier();
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_front(const float* __restrict__
         a[k] = (base + k < n) ? fabsf(sc) : 0.0f;
       }
       double Senv = Scar[NCH];
-      double e = follower_solve(a, P.glue_A, P.glue_R, Senv, slots.next());
+      double e = follower_solve(a, P.glue_A, P.glue_R, Senv, glT, slots.next());
       if (threadIdx.x == 0) Scar[NCH] = Senv;
 #pragma unroll
       for (int k = 0; k < C; k++) {

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
   double Spk = 0;
   int ring = 0;                                        // stays 0 while W <= kTile
   for (int i = threadIdx.x; i < padi(W) + 8; i += kThreads) tail[i] = 0;
+  __shared__ double pkT[C + 2];                        // follower_al_table of the peak follower
+  follower_al_table(P.pa, P.pr, pkT);
   lds_barrier();
   // segment [T0, T1) of the track's tiles, entered `warm` tiles early: the RMS window is exact once W samples (10 ms; the
   // warm-up is 25 tiles at 48 kHz and scales with the rate) have been seen, and the peak follower forgets as exp(-k / (50 ms))
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void k_lim_tm(const float* __restrict__ i
 #pragma unroll
     for (int k = 0; k < C; k++) pre[padi(threadIdx.x * C + k)] = off + q[k];
     // peak follower (dsp-worker.js:334-351)
-    double e = follower_solve(pk, P.pa, P.pr, Spk, slots.next());      // contains barriers: pre[] is visible after it
+    double e = follower_solve(pk, P.pa, P.pr, Spk, pkT, slots.next());      // contains barriers: pre[] is visible after it
     float tmv[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {

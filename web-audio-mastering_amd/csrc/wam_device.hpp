@@ -491,28 +491,6 @@ __device__ __forceinline__ double solve_piecewise(Run run, double guess, double&
   return start;
 }
 
-// Branchy attack/release follower (dsp-worker.js:1308-1312, :345-349;
-// multiband-transient.js:219-230): e' = (a > e) ? A e + (1-A) a : R e + (1-R) a.
-// a[] = rectified input of the chunk.  Returns the chunk's true start value.
-template <class T>
-__device__ __forceinline__ double follower_solve(const T a[C], double A, double R, double& S, double* lds) {
-  // (al, be) are functions of the branch pattern only (never of e0's low bits), so the fixed-point test of
-  // solve_piecewise terminates as soon as the pattern is stable.  The envelope itself is materialised by follower_step.
-  auto run = [&](double e0, double& al, double& be, unsigned& m) {
-    al = 1; be = 0; m = 0;
-#pragma unroll
-    for (int n = 0; n < C; n++) {
-      const double e = fma(al, e0, be);
-      const double an = (double)a[n];
-      const bool up = an > e;
-      const double c = up ? A : R;
-      m = (m << 1) | (unsigned)up;
-      be = fma(c, be - an, an);              // = c be + (1 - c) a
-      al = c * al;
-    }
-  };
-  return solve_piecewise(run, S, S, lds);
-}
 // Multiplier table of a follower's chunk maps: tab[p] = A^p R^(C-p), p = 0..C attack steps among the chunk's C (LDS; written by
 // threads 0..C of the workgroup, a barrier before the first use is the caller's).
 __device__ __forceinline__ void follower_al_table(double A, double R, double* tab) {
@@ -520,6 +498,96 @@ __device__ __forceinline__ void follower_al_table(double A, double R, double* ta
   if (p <= C) { double v = 1; for (int i = 0; i < C; i++) v *= (i < p ? A : R); tab[p] = v; }
 }
 
+// Branchy attack/release follower (dsp-worker.js:1308-1312, :345-349;
+// multiband-transient.js:219-230): e' = (a > e) ? A e + (1-A) a : R e + (1-R) a.
+// a[] = rectified input of the chunk.  Returns the chunk's true start value; the envelope itself is materialised by the caller
+// with the reference's own expression (follower_step).  Tab = follower_al_table(A, R) in LDS.
+// The same scheme as the pair solver below, for one follower: two passes in single precision that only have to get the branch
+// pattern roughly right (no convergence vote), then double-precision passes in max-form - e' = a + max(A d, R d), d = e - a, no
+// compare and no 64-bit select; the pattern bit is the sign of d, the chunk map's multiplier follows from the number of attack
+// steps through the table - until the pattern reproduces itself: the answer is the sequential one whatever the first guess was.
+// (Round 2's generic policy iteration with per-step selects took 3.4-4.3 double passes of 8 instructions per step here.)
+template <class T>
+__device__ __forceinline__ double follower_solve(const T& a, double A, double R, double& S, const double* Tab, double* lds) {
+  const int lane = lane_id(), wave = wave_id();
+  const double S_in = S;
+  double s = S;
+#ifndef WAM_NO_F32_PRESOLVE
+  {
+    const float Af = (float)A, Rf = (float)R, Sin = (float)S;
+    float st = Sin;
+#pragma unroll 1
+    for (int pre = 0; pre < 2; pre++) {
+      float al = 1.0f, be = 0.0f;
+#pragma unroll
+      for (int n = 0; n < C; n++) {
+        const float an = (float)a[n];
+        const float e = al * st + be;
+        const float c = (an > e) ? Af : Rf;
+        be = c * (be - an) + an;
+        al = c * al;
+      }
+#define WAM_PRE1_STEP(CTRL, RM) { const float ta = dpp_f<CTRL, RM>(1.0f, al), tb = dpp_f<CTRL, RM>(0.0f, be); be = al * tb + be; al = al * ta; }
+      WAM_PRE1_STEP(0x111, 0xF) WAM_PRE1_STEP(0x112, 0xF) WAM_PRE1_STEP(0x114, 0xF) WAM_PRE1_STEP(0x118, 0xF)
+      WAM_PRE1_STEP(0x142, 0xA) WAM_PRE1_STEP(0x143, 0xC)
+#undef WAM_PRE1_STEP
+      float* ldsf = (float*)lds + 8 * (pre & 1);                        // two regions of 8 floats in the slot, one per pass
+      if (lane == 63) { ldsf[2 * wave] = al; ldsf[2 * wave + 1] = be; }
+      const float xa = dpp_f<0x138, 0xF>(1.0f, al), xb = dpp_f<0x138, 0xF>(0.0f, be);
+      lds_barrier();
+      float w = Sin, my = Sin;
+#pragma unroll
+      for (int k = 0; k < kWaves; k++) {
+        w = ldsf[2 * k] * w + ldsf[2 * k + 1];
+        if (k + 1 == wave) my = w;
+      }
+      st = xa * my + xb;
+    }
+    lds_barrier();                                              // the loop below rewrites the slot
+    s = (double)st;
+  }
+#endif
+  double prev = s;
+  unsigned pm = 0;
+  const double sg = R >= A ? 1.0 : -1.0, cA = sg * A, cR = sg * R;
+  int it = 0, vp = 0;
+  for (; it < 260; it++) {
+    double e = s;
+    unsigned m = 0;
+#pragma unroll
+    for (int n = 0; n < C; n++) {
+      const double an = (double)a[n];
+      const double d = e - an;
+      m = __builtin_amdgcn_alignbit(m, (unsigned)__double2hiint(d), 31);         // (m << 1) | (d < 0)
+      e = fma(sg, fmax(cA * d, cR * d), an);
+    }
+    // same pattern as in the previous pass = same map = the scan would reproduce the start values: they are the solution and S
+    // holds the carry of that scan (the vote is also the barrier that lets lds be rewritten)
+    if (it > 0 && !block_any(m != pm, vp)) break;
+    pm = m;
+    double al = Tab[__builtin_popcount(m)];
+    double be = fma(-al, s, e);
+    wave_scan_affine(al, be);
+    if (lane == 63) { lds[2 * wave] = al; lds[2 * wave + 1] = be; }
+    const double xa = dpp_d<0x138, 0xF>(1.0, al), xb = dpp_d<0x138, 0xF>(0.0, be);
+    lds_barrier();
+    double w = S_in, my = S_in;
+#pragma unroll
+    for (int k = 0; k < kWaves; k++) {
+      w = lds[2 * k] * w + lds[2 * k + 1];
+      if (k + 1 == wave) my = w;
+    }
+    const double ns = xa * my + xb;
+    S = w;
+    // a tie to the last bit can flip with the ulp its own flip causes (a 2-cycle between two start vectors that are both valid to
+    // rounding): detected from the 4th pass on (one more vote), then ended
+    if (it >= 3 && !block_any(__double_as_longlong(ns) != __double_as_longlong(prev), vp)) { s = ns; break; }
+    prev = s;
+    s = ns;
+  }
+  count_iters(0, it + 1);
+  return s;
+}
 // Two followers over the same input (the fast and slow envelopes of the transient shaper), solved in one iteration
 // loop: their runs and scans interleave (instruction-level parallelism for the dependent chains) and they share the
 // barriers; the loop ends when both start values reproduce themselves.  lds: 16 doubles.
