@@ -53,7 +53,8 @@ int wam_debug_counters(uint64_t out[8], int reset);
 int wam_probe_shader_clock(double millis, double* mhz);
 
 /* Host-pointer staging knobs of wam_tune: "stage_pinned" (1: pinned rings + copy threads, csrc/staging.hip; 0: hipMemcpyAsync on
- * the caller's pageable memory), "stage_threads" (1..8), "host_group" (tracks per staging group of wam_batch_render);
+ * the caller's pageable memory), "stage_threads" (1..8), "stage_nt" (1: the staging copies use non-temporal stores),
+ * "host_group" (tracks per staging group of wam_batch_render);
  * "stft_literal" 0 fastest kernel, 1 the literal loop nest of spectrogram.js, 2 the register-blocked workgroup kernel;
  * "exc_peaks" 0: tape warmth's window peaks by their own pass over the batch even when the exciter could leave them behind;
  * "dh_win_lds" 0: the de-harsh kernels' instantiation that reads the Hann table from global memory (both: results unchanged). */

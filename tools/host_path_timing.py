@@ -39,6 +39,19 @@ wam.batch_render(tracks, sr, s, "export", outs=outs)
 dt = time.perf_counter() - t0
 print(f"batch_render into reused output arrays: {T} tracks in {dt * 1e3:.0f} ms = {T * 180 / dt:.0f} x realtime")
 
+if os.environ.get("WAM_HOST_NT"):
+    for nt in (0, 1, 0, 1, 0, 1):
+        wam.tune("stage_nt", nt)
+        t0 = time.perf_counter()
+        wam.batch_render(tracks, sr, s, "export")
+        dt = time.perf_counter() - t0
+        print(f"stage_nt {nt}: {T} tracks in {dt * 1e3:.0f} ms = {T * 180 / dt:.0f} x realtime", flush=True)
+    for nt in (0, 1, 0, 1):
+        wam.tune("stage_nt", nt)
+        t0 = time.perf_counter(); k = 5
+        for _ in range(k): wam.render_full_chain(x, sr, s, "export")
+        dt = (time.perf_counter() - t0) / k
+        print(f"stage_nt {nt}: render_full_chain {dt * 1e3:.1f} ms", flush=True)
 if os.environ.get("WAM_HOST_SWEEP"):
     for hg in (8, 16, 32):
         for th in (4, 8):

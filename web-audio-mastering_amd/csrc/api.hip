@@ -257,6 +257,7 @@ int wam_tune(const char* key, int64_t value) {
   else if (k == "stage_threads" && value >= 1 && value <= 8) t.stage_threads = value;
   else if (k == "host_group" && value >= 1 && value <= 256) t.host_group = value;
   else if (k == "exc_peaks") t.exc_peaks = value != 0;
+  else if (k == "stage_nt") t.stage_nt = value != 0;
   else if (k == "dh_win_lds") t.dh_win_lds = value != 0;
   else if (k == "reset") t = wam::Tuning();
   else { wam::set_error("wam_tune: unknown key or value out of range: %s = %lld", key, (long long)value); return WAM_ERR_INVALID; }

@@ -10,6 +10,10 @@
 // 39 GB/s up, 34 GB/s down with four threads.  All DMAs go to the caller's stream, so they are ordered with the kernels there.
 #include "wam_common.hpp"
 #include <cstring>
+#include <cstdint>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <mutex>
 #include <thread>
 
@@ -45,6 +49,30 @@ PinRing* ring_acquire() {
 void ring_release(PinRing* r) { std::lock_guard<std::mutex> lk(g_ring_mu); g_rings.push_back(r); }
 
 struct Piece { char* host; char* dev; size_t len; };
+
+// memcpy with non-temporal stores (SSE2: part of every x86-64).  Neither destination is read again by this core - a pinned slot is
+// read by the DMA engine, the caller's output array some time later - so the lines need not be fetched for ownership nor kept in
+// the cache: half the memory traffic of the store side of a plain memcpy at these sizes (glibc switches to such stores only above
+// a threshold that a 4 MiB piece does not reach when many threads share the cache).
+inline void copy_streaming(void* dst, const void* src, size_t len) {
+#if defined(__x86_64__) && defined(__SSE2__)
+  if (!tuning().stage_nt || len < 4096) { std::memcpy(dst, src, len); return; }
+  char* d = (char*)dst; const char* s = (const char*)src;
+  const size_t head = (16 - ((uintptr_t)d & 15)) & 15;                 // stores must be 16-byte aligned, loads need not be
+  if (head) { std::memcpy(d, s, head); d += head; s += head; len -= head; }
+  size_t n64 = len / 64;
+  for (; n64; n64--, d += 64, s += 64) {
+    const __m128i a = _mm_loadu_si128((const __m128i*)s), b = _mm_loadu_si128((const __m128i*)(s + 16));
+    const __m128i c = _mm_loadu_si128((const __m128i*)(s + 32)), e = _mm_loadu_si128((const __m128i*)(s + 48));
+    _mm_stream_si128((__m128i*)d, a); _mm_stream_si128((__m128i*)(d + 16), b);
+    _mm_stream_si128((__m128i*)(d + 32), c); _mm_stream_si128((__m128i*)(d + 48), e);
+  }
+  _mm_sfence();
+  if (len & 63) std::memcpy(d, s, len & 63);
+#else
+  std::memcpy(dst, src, len);
+#endif
+}
 }  // namespace
 
 void staging_trim() {
@@ -98,7 +126,7 @@ int staged_copy(const HostSeg* segs, int nsegs, bool to_device, hipStream_t stre
         const Piece& pc = pieces[mine[j]];
         const int s = slots[j % ns];
         if (j >= ns && hipEventSynchronize(ring->ev[s]) != hipSuccess) { rcs[k] = 1; return; }     // the slot's previous DMA
-        std::memcpy(ring->base + (size_t)s * kPiece, pc.host, pc.len);
+        copy_streaming(ring->base + (size_t)s * kPiece, pc.host, pc.len);
         if (hipMemcpyAsync(pc.dev, ring->base + (size_t)s * kPiece, pc.len, hipMemcpyHostToDevice, stream) != hipSuccess ||
             hipEventRecord(ring->ev[s], stream) != hipSuccess) { rcs[k] = 1; return; }
       }
@@ -116,7 +144,7 @@ int staged_copy(const HostSeg* segs, int nsegs, bool to_device, hipStream_t stre
         const Piece& pc = pieces[mine[j]];
         const int s = slots[j % ns];
         if (hipEventSynchronize(ring->ev[s]) != hipSuccess) { rcs[k] = 1; return; }
-        std::memcpy(pc.host, ring->base + (size_t)s * kPiece, pc.len);
+        copy_streaming(pc.host, ring->base + (size_t)s * kPiece, pc.len);
         if (issued < mine.size() && !issue()) { rcs[k] = 1; return; }                                // the slot is free again
       }
     }

@@ -99,6 +99,7 @@ struct Tuning {
   int64_t stage_pinned = 1;       // host-pointer entry points: 1 = copies through the pinned ring (staging.hip), 0 = hipMemcpyAsync on the caller's pageable memory
   int64_t stage_threads = 4;      // copy threads per staged copy (1..8)
   int64_t dh_win_lds = 1;         // 0 = the de-harsh kernels read the Hann table from global memory even when it mirrors (the path a host whose cos() does not mirror takes; test hook)
+  int64_t stage_nt = 1;           // staging copies with non-temporal stores (0: plain memcpy)
   int64_t exc_peaks = 1;          // 1 = the exciter also produces tape warmth's window peaks (0: k_win_peak reads the batch again; test hook)
   int64_t host_group = 16;        // wam_batch_render: tracks per staging group (each group is one device batch)
 };
