@@ -156,6 +156,31 @@ def test_host_batch_equals_single():
         wam.batch_render(tracks[:2], 0.0, s, "export")
 
 
+def test_staging_variants_move_the_same_bytes():
+    """The host-pointer path copies through pinned rings with non-temporal stores by default (csrc/staging.hip); with plain memcpy
+    (stage_nt 0) and with the runtime's own staging (stage_pinned 0) the rendered samples are the same to the bit.  1.3 M samples
+    per channel: above the 1 MiB threshold of the rings, not a multiple of anything, channels at odd byte offsets of a base array."""
+    sr, n = 48000, 1300003
+    base = [np.zeros(n + 3, dtype=np.float32) for _ in range(2)]
+    x0 = O.synth(3, 2, n, sr, {"amp": 1.3, "clickAmp": 0.5})
+    x = []
+    for c in range(2):
+        v = base[c][1 + c:1 + c + n]                   # 4- and 8-byte offsets from the allocation: unaligned for 16-byte stores
+        v[:] = x0[c]
+        x.append(v)
+    s = dict(wam.DEFAULT_SETTINGS, deharsh=False, addPunch=False)
+    try:
+        want, wres = wam.render_full_chain(x, sr, s, "export")
+        for key, val in (("stage_nt", 0), ("stage_pinned", 0)):
+            wam.tune(key, val)
+            got, gres = wam.render_full_chain(x, sr, s, "export")
+            wam.tune("reset")
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), key
+            assert gres.lufs == wres.lufs
+    finally:
+        wam.tune("reset")
+
+
 def test_multi_device_batch_equals_single():
     """wam_batch_render_multi: contiguous track ranges per device entry, one host thread + streams per entry,
     results concatenated in track order.  One GPU on the box: devices = [0, 0] are two workers on it; [0, 0, 0] over 23 tracks gives
